@@ -1,0 +1,169 @@
+"""Pin oracle/wm_oracle.py to the numbers the reference itself produced
+(tests/golden/main16_golden.npz, written by tests/golden/make_golden.py in the build
+container).  CPU only; needs neither the reference nor a GPU."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import recipes as R
+from oracle import wm_oracle as O
+
+TOL = 2e-6   # fp32 CPU vs fp32 CPU; thread-count dependent summation order only
+
+
+def _sha(sd):
+    h = hashlib.sha256()
+    for k, v in sd.items():
+        h.update(k.encode())
+        h.update(v.detach().cpu().contiguous().numpy().tobytes())
+    return np.frombuffer(h.digest(), dtype=np.uint8)
+
+
+def _close(a, b, tol=TOL):
+    a = torch.as_tensor(np.asarray(a)).double()
+    b = torch.as_tensor(np.asarray(b)).double() if not torch.is_tensor(b) else b.detach().double()
+    scale = max(1.0, float(a.abs().max()))
+    err = float((a - b).abs().max()) / scale
+    assert err <= tol, f"max scaled err {err:.3e} > {tol}"
+
+
+@pytest.fixture(scope="module")
+def states(golden):
+    gsd, dsd = R.reference_layout_init()
+    assert np.array_equal(_sha(gsd), golden["init_sha_g"]), "default-init recipe no longer reproduces the reference init"
+    assert np.array_equal(_sha(dsd), golden["init_sha_d"])
+    R.perturb_bn_(gsd, seed=R.BN_SEED_G)
+    R.perturb_bn_(dsd, seed=R.BN_SEED_D)
+    assert np.array_equal(_sha(gsd), golden["state_sha_g"])
+    assert np.array_equal(_sha(dsd), golden["state_sha_d"])
+    return gsd, dsd
+
+
+def test_state_layout(states):
+    gsd, dsd = states
+    assert len(gsd) == 53 and len(dsd) == 32
+    assert gsd["embedding.weight"].shape == (65536, 64)
+    assert gsd["decoder.0.weight"].shape == (64, 64, 7)
+    assert dsd["model.3.weight"].shape == (17, 64, 1)
+
+
+def test_g1_eval_forward(golden, states):
+    gsd, dsd = states
+    s = O.synthetic_clips(2, seed=1234)
+    msg = torch.from_numpy(golden["g1_message"])
+    with torch.no_grad():
+        taps = {}
+        d = O.generator_forward(gsd, s, msg, training=False, taps=taps)
+        _close(golden["g1_delta"], d)
+        _close(golden["g1_delta_nomsg_sub"], O.generator_forward(gsd, s, None)[..., ::97])
+        dp = O.postprocess(d)
+        _close(golden["g1_delta_post"], dp)
+        lg = O.detector_forward(dsd, torch.cat([s + dp, s], 0))
+        _close(golden["g1_logits_sub"], lg[:, ::97, :])
+        chk = golden["g1_logits_chk"]
+        assert abs(float(lg.double().sum()) - chk[0]) <= 1e-6 * chk[1]
+        for k in ("enc0", "enc", "lstm", "dec0", "dec1"):
+            _close(golden[f"g1_tap_{k}_sub"], taps[k][..., ::97])
+        _close(golden["g1_tap_lstm_tail"], taps["lstm"][:, :, -64:])
+
+
+def test_explicit_lstm_loop_matches(golden, states):
+    """the hand-written time loop (independent of aten::lstm) reproduces the reference LSTM tap"""
+    gsd, _ = states
+    s = O.synthetic_clips(2, seed=1234)
+    with torch.no_grad():
+        taps = {}
+        O.generator_forward(gsd, s, None, taps=taps)
+        n = 291  # 3 sub-sampled frames' worth
+        xs = taps["enc"][:, :, :n].permute(0, 2, 1)
+        h = O.lstm_forward(xs, gsd["lstm.weight_ih_l0"], gsd["lstm.weight_hh_l0"], gsd["lstm.bias_ih_l0"],
+                           gsd["lstm.bias_hh_l0"]).permute(0, 2, 1)
+    _close(golden["g1_tap_lstm_sub"][:, :, :3], h[:, :, ::97])
+
+
+def test_g2_train_step(golden, states):
+    gsd, dsd = states
+    g2 = {k: v.clone().requires_grad_(v.dtype.is_floating_point and "running" not in k) for k, v in gsd.items()}
+    d2 = {k: v.clone().requires_grad_(v.dtype.is_floating_point and "running" not in k) for k, v in dsd.items()}
+    s = O.synthetic_clips(4, seed=1235)
+    msg = torch.from_numpy(golden["g2_message"])
+    gst, dst = {}, {}
+    total, out = O.step_losses(g2, d2, s, msg, training=True, g_stats=gst, d_stats=dst)
+    total.backward()
+    for k in ("l1", "mel", "loud", "loc", "bce", "hf", "total"):
+        _close(golden[f"g2_{k}"], out[k])
+    _close(golden["g2_delta_raw_sub"], out["delta_raw"][..., ::97])
+    _close(golden["g2_delta_sub"], out["delta"][..., ::97])
+    _close(golden["g2_logits_sub"], out["logits"][:, ::97, :])
+    gtol = 2e-5   # gradients: relative to the tensor's max
+    def gclose(name, g):
+        ref = torch.from_numpy(golden[name]).double()
+        err = float((ref - g.double()).abs().max()) / float(ref.abs().max())
+        assert err <= gtol, f"{name}: {err:.3e}"
+    gclose("g2_grad_g_encoder0_weight", g2["encoder.0.weight"].grad)
+    gclose("g2_grad_g_lstm_whh", g2["lstm.weight_hh_l0"].grad)
+    gclose("g2_grad_g_lstm_wih", g2["lstm.weight_ih_l0"].grad)
+    gclose("g2_grad_g_emb_rows", g2["embedding.weight"].grad[msg])
+    gclose("g2_grad_g_dec0_weight_sub", g2["decoder.0.weight"].grad[::4, ::4])
+    gclose("g2_grad_g_enc1_b0_weight_sub", g2["encoder.1.block.0.weight"].grad[::4, ::4])
+    gclose("g2_grad_g_enc1_bn1_weight", g2["encoder.1.block.1.weight"].grad)
+    gclose("g2_grad_d_model3_weight", d2["model.3.weight"].grad)
+    gclose("g2_grad_d_model0_weight", d2["model.0.weight"].grad)
+    gclose("g2_grad_d_m1_bn4_bias", d2["model.1.block.4.bias"].grad)
+    _close(golden["g2_new_g_enc1_bn1_rm"], gst["encoder.1.block.1.running_mean"])
+    _close(golden["g2_new_g_enc1_bn1_rv"], gst["encoder.1.block.1.running_var"])
+    _close(golden["g2_new_d_m2_bn4_rm"], dst["model.2.block.4.running_mean"])
+    _close(golden["g2_new_d_m2_bn4_rv"], dst["model.2.block.4.running_var"])
+    assert int(gst["encoder.1.block.1.num_batches_tracked"]) == 4
+
+
+def test_g3_shipped_detector_checkpoint(golden):
+    ck = np.load(os.path.join(os.path.dirname(__file__), "golden", "detector_best_unprefixed.npz"))
+    sd = {k: torch.from_numpy(ck[k]) for k in ck.files}
+    assert len(sd) == 32 and int(sd["model.1.block.1.num_batches_tracked"]) == 4500
+    s = O.synthetic_clips(2, seed=1234)
+    with torch.no_grad():
+        lg = O.detector_forward(sd, s)
+    _close(golden["g3_logits_sub"], lg[:, ::97, :])
+    _close(golden["g3_mean_prob"], torch.sigmoid(lg[:, :, 0]).mean(dim=1))
+
+
+def test_g4_postprocess_and_losses(golden):
+    dbig = 0.03 * torch.randn(3, 1, 16000, generator=torch.Generator().manual_seed(77))
+    dsmall = 0.001 * torch.randn(3, 1, 16000, generator=torch.Generator().manual_seed(78))
+    for nm, d in (("big", dbig), ("small", dsmall)):
+        po = O.postprocess(d)
+        _close(golden[f"g4_post_{nm}_sub"], po[..., ::97])
+        _close(golden[f"g4_hf_{nm}"], O.high_freq_penalty(po))
+    # the reference FIR is numerically an all-pass: centre tap 1, the rest <= 1e-7
+    k = O.fir_kernel()
+    _close(golden["g4_fir_kernel"], k)
+    assert abs(float(k[50]) - 1.0) < 1e-6 and float(k.abs().sum() - k[50].abs()) < 1e-5
+    s3 = O.synthetic_clips(3, seed=99)
+    _close(golden["g4_loud"], O.loudness_loss(s3, s3 + dbig.clamp(-0.02, 0.02)))
+    _close(golden["g4_mel_restated"], O.mel_loss(s3, s3 + dbig.clamp(-0.02, 0.02)))
+
+
+def test_mel_filterbank_restatement(golden):
+    fb = O.mel_filterbank()
+    assert fb.shape == (513, 64) and float(fb.min()) >= 0.0
+    _close(golden["mel_fbank_colsum"], fb.sum(0))
+    tfm = pytest.importorskip("transformers.audio_utils")
+    fb2 = tfm.mel_filter_bank(513, 64, 0.0, 8000.0, 16000, norm=None, mel_scale="htk")
+    assert float(np.abs(fb.numpy() - fb2).max()) < 2e-5
+
+
+def test_bn_explicit_matches_aten():
+    x = torch.randn(3, 5, 211, generator=torch.Generator().manual_seed(0)) * 2 + 0.3
+    w, b = torch.rand(5) + 0.5, torch.randn(5)
+    rm, rv = torch.randn(5) * 0.1, torch.rand(5) + 0.5
+    for tr in (True, False):
+        rm2, rv2 = rm.clone(), rv.clone()
+        y = torch.nn.functional.batch_norm(x, rm2, rv2, w, b, tr, 0.1, 1e-5)
+        y2, nrm, nrv = O.bn_explicit(x, w, b, rm, rv, tr)
+        _close(y, y2, 1e-5)
+        _close(rm2, nrm, 1e-6)
+        _close(rv2, nrv, 1e-6)
