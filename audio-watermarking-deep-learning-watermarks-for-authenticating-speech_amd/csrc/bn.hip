@@ -1,0 +1,171 @@
+// BatchNorm1d(64) pieces that sit between the MFMA convolutions of a ResBlock
+// (py/main16.py:112-125).  The convolution kernels fuse "normalise + ReLU" into their
+// loads and the per-channel sum / sum-of-squares into their epilogues; what is left is
+//   * finalize: partial sums -> (scale, shift), saved (mean, invstd), running statistics
+//   * the block tail  out = relu(x + bn2(y2))
+//   * backward: dz2 = g * (out > 0) with the two per-channel reductions BN backward needs,
+//     and the per-channel constants that let the next kernel rebuild dy on load.
+#include "wm_common.hpp"
+using namespace wm;
+
+namespace {
+
+// partials: [nparts][2][64] (sum, sum of squares) ; one 64-thread block
+__global__ void bn_finalize_kernel(const float* __restrict__ partials, int nparts, double count,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float* running_mean, float* running_var, long long* num_batches_tracked,
+                                   float momentum, float eps, float* scale, float* shift, float* save_mean,
+                                   float* save_invstd) {
+    const int c = threadIdx.x;
+    double s1 = 0.0, s2 = 0.0;
+    for (int p = 0; p < nparts; ++p) {
+        s1 += (double)partials[(size_t)p * 128 + c];
+        s2 += (double)partials[(size_t)p * 128 + 64 + c];
+    }
+    const double mean = s1 / count;
+    double var = s2 / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const double invstd = 1.0 / sqrt(var + (double)eps);
+    const float sc = (float)((double)gamma[c] * invstd);
+    scale[c] = sc;
+    shift[c] = (float)((double)beta[c] - mean * (double)gamma[c] * invstd);
+    save_mean[c] = (float)mean;
+    save_invstd[c] = (float)invstd;
+    if (running_mean) {
+        const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+        running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * mean);
+        running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * unbiased);
+        if (c == 0 && num_batches_tracked) *num_batches_tracked += 1;
+    }
+}
+
+__global__ void bn_eval_kernel(const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
+                               float* scale, float* shift) {
+    const int c = threadIdx.x;
+    const float inv = 1.0f / sqrtf(rv[c] + eps);
+    scale[c] = gamma[c] * inv;
+    shift[c] = beta[c] - rm[c] * gamma[c] * inv;
+}
+
+// out = relu(x + y*scale[c] + shift[c]);  grid (rows = B*64), float4 over T
+__global__ __launch_bounds__(256) void bn_add_relu_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                          const float* __restrict__ scale, const float* __restrict__ shift,
+                                                          float* __restrict__ out, int T4) {
+    const int row = blockIdx.x, c = row & 63;
+    const float sc = scale[c], sh = shift[c];
+    const float4* xr = reinterpret_cast<const float4*>(x) + (size_t)row * T4;
+    const float4* yr = reinterpret_cast<const float4*>(y) + (size_t)row * T4;
+    float4* orow = reinterpret_cast<float4*>(out) + (size_t)row * T4;
+    for (int i = threadIdx.x; i < T4; i += 256) {
+        const float4 a = xr[i], b = yr[i];
+        float4 o;
+        o.x = fmaxf(a.x + fmaf(b.x, sc, sh), 0.f);
+        o.y = fmaxf(a.y + fmaf(b.y, sc, sh), 0.f);
+        o.z = fmaxf(a.z + fmaf(b.z, sc, sh), 0.f);
+        o.w = fmaxf(a.w + fmaf(b.w, sc, sh), 0.f);
+        orow[i] = o;
+    }
+}
+
+// dz = g * (out > 0);  partial[b][0][c] = sum dz, partial[b][1][c] = sum dz*y   (row = b*64+c)
+__global__ __launch_bounds__(256) void relu_bwd_reduce_kernel(const float* __restrict__ g, const float* __restrict__ out,
+                                                              const float* __restrict__ y, float* __restrict__ dz,
+                                                              float* __restrict__ partial, int T4) {
+    __shared__ float scratch[8];
+    const int row = blockIdx.x, b = row >> 6, c = row & 63;
+    const float4* gr = reinterpret_cast<const float4*>(g) + (size_t)row * T4;
+    const float4* orow = reinterpret_cast<const float4*>(out) + (size_t)row * T4;
+    const float4* yr = reinterpret_cast<const float4*>(y) + (size_t)row * T4;
+    float4* dr = reinterpret_cast<float4*>(dz) + (size_t)row * T4;
+    float s1 = 0.f, s2 = 0.f;
+    for (int i = threadIdx.x; i < T4; i += 256) {
+        const float4 gg = gr[i], oo = orow[i], yy = yr[i];
+        float4 d;
+        d.x = oo.x > 0.f ? gg.x : 0.f;
+        d.y = oo.y > 0.f ? gg.y : 0.f;
+        d.z = oo.z > 0.f ? gg.z : 0.f;
+        d.w = oo.w > 0.f ? gg.w : 0.f;
+        dr[i] = d;
+        s1 += (d.x + d.y) + (d.z + d.w);
+        s2 += fmaf(d.x, yy.x, d.y * yy.y) + fmaf(d.z, yy.z, d.w * yy.w);
+    }
+    s1 = block_sum<4>(s1, scratch);
+    s2 = block_sum<4>(s2, scratch + 4);
+    if (threadIdx.x == 0) {
+        partial[(size_t)b * 128 + c] = s1;
+        partial[(size_t)b * 128 + 64 + c] = s2;
+    }
+}
+
+// partials [nparts][2][64] = (sum dz, sum dz*y_raw)  ->  dy = A*dz + Bc + Cc*y ; dgamma ; dbeta
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ partials, int nparts, double count,
+                                       const float* __restrict__ gamma, const float* __restrict__ save_mean,
+                                       const float* __restrict__ save_invstd, float* A, float* Bc, float* Cc,
+                                       float* dgamma, float* dbeta, int accumulate, int eval_mode) {
+    const int c = threadIdx.x;
+    double s1 = 0.0, s2 = 0.0;
+    for (int p = 0; p < nparts; ++p) {
+        s1 += (double)partials[(size_t)p * 128 + c];
+        s2 += (double)partials[(size_t)p * 128 + 64 + c];
+    }
+    const double mu = save_mean[c], is = save_invstd[c], ga = gamma[c];
+    const double sxh = (s2 - mu * s1) * is;            // sum dz * yhat
+    A[c] = (float)(ga * is);
+    // eval mode: the statistics are constants (running stats), only the scale survives
+    Cc[c] = eval_mode ? 0.f : (float)(-ga * is * is * sxh / count);
+    Bc[c] = eval_mode ? 0.f : (float)(-ga * is * s1 / count + ga * is * is * mu * sxh / count);
+    if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)sxh : (float)sxh;
+    if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)s1 : (float)s1;
+}
+
+}  // namespace
+
+extern "C" {
+
+// Train-mode BatchNorm finalize (py/main16.py:117,120 in .train()): batch mean / biased var for
+// normalisation, running stats with momentum and unbiased var, num_batches_tracked += 1.
+int wm_bn_finalize(const float* partials, int nparts, double count, const float* gamma, const float* beta,
+                   float* running_mean, float* running_var, long long* num_batches_tracked, float momentum, float eps,
+                   float* scale, float* shift, float* save_mean, float* save_invstd, hipStream_t stream) {
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(64), 0, stream, partials, nparts, count, gamma, beta,
+                       running_mean, running_var, num_batches_tracked, momentum, eps, scale, shift, save_mean, save_invstd);
+    WM_CHECK_LAUNCH();
+    return 0;
+}
+
+// Eval-mode BatchNorm folded to per-channel (scale, shift) from the running statistics.
+int wm_bn_eval_scale_shift(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                           float eps, float* scale, float* shift, hipStream_t stream) {
+    hipLaunchKernelGGL(bn_eval_kernel, dim3(1), dim3(64), 0, stream, gamma, beta, running_mean, running_var, eps, scale, shift);
+    WM_CHECK_LAUNCH();
+    return 0;
+}
+
+// ResBlock tail: out = relu(x + y2*scale + shift)   (py/main16.py:125)
+int wm_bn_add_relu(const float* x, const float* y2, const float* scale, const float* shift, float* out, int B, int T,
+                   hipStream_t stream) {
+    if (T & 3) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(bn_add_relu_kernel, dim3(B * 64), dim3(256), 0, stream, x, y2, scale, shift, out, T / 4);
+    WM_CHECK_LAUNCH();
+    return 0;
+}
+
+// Backward of the tail: dz = g*(out>0) (also the residual-path gradient), partial[B][2][64].
+int wm_relu_bwd_reduce(const float* g, const float* out, const float* y2, float* dz, float* partial, int B, int T,
+                       hipStream_t stream) {
+    if (T & 3) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(relu_bwd_reduce_kernel, dim3(B * 64), dim3(256), 0, stream, g, out, y2, dz, partial, T / 4);
+    WM_CHECK_LAUNCH();
+    return 0;
+}
+
+int wm_bn_bwd_finalize(const float* partials, int nparts, double count, const float* gamma, const float* save_mean,
+                       const float* save_invstd, float* A, float* Bc, float* Cc, float* dgamma, float* dbeta,
+                       int accumulate, int eval_mode, hipStream_t stream) {
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(64), 0, stream, partials, nparts, count, gamma, save_mean,
+                       save_invstd, A, Bc, Cc, dgamma, dbeta, accumulate, eval_mode);
+    WM_CHECK_LAUNCH();
+    return 0;
+}
+
+}  // extern "C"

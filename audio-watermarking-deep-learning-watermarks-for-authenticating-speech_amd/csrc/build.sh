@@ -1,0 +1,17 @@
+#!/usr/bin/env bash
+# Build libwm_hip.so for gfx950 (cross-compiles without a GPU).  Usage: csrc/build.sh [-j N]
+set -euo pipefail
+cd "$(dirname "$0")"
+HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result"
+mkdir -p obj
+pids=()
+for f in conv64 bn small_convs lstm postproc stft_loss losses; do
+  if [ ! -f obj/$f.o ] || [ $f.hip -nt obj/$f.o ] || [ wm_common.hpp -nt obj/$f.o ]; then
+    $HIPCC $FLAGS -c $f.hip -o obj/$f.o &
+    pids+=($!)
+  fi
+done
+for p in "${pids[@]:-}"; do [ -n "$p" ] && wait $p; done
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o ../libwm_hip.so obj/*.o
+echo "built $(cd .. && pwd)/libwm_hip.so"

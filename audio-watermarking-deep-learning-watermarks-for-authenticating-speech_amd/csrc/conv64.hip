@@ -1,0 +1,605 @@
+// 64 -> 64 channel 1-D convolutions on [B,64,T] fp32 frames as implicit GEMMs on the gfx950
+// fp32 matrix cores (v_mfma_f32_32x32x2_f32: exact fp32, frees the VALU for the fused
+// prologue / epilogue work).
+//
+// Replaces, for the hot path of py/main16.py:
+//   * ResBlock's two Conv1d(64,64,3,padding=1) (+ the BatchNorm1d / ReLU around them)   :115-121
+//   * Generator.decoder[0] = ConvTranspose1d(64,64,7,padding=3) (+ the embedding add)      :144,156-159
+//   * their data-gradients (same kernel, re-packed weights) and weight-gradients.
+//
+// One persistent 256-thread workgroup per CU streams (clip, time-tile) tiles:
+//   global --(dwordx4, software-pipelined one tile ahead, through registers so the prologue
+//   transform can be applied)--> LDS [64][NT+halo]  --ds_read_b32--> MFMA B operand
+//   packed weights [tap][cin][cout] live in LDS for the whole kernel --> MFMA A operand
+//   D tile (cout x time) leaves the accumulators as 128-B row segments (time is contiguous).
+#include "wm_common.hpp"
+using namespace wm;
+
+namespace {
+
+enum { PRO_NONE = 0, PRO_BNRELU = 1, PRO_ADDVEC = 2, PRO_BNBWD = 3 };
+enum { EPI_BIAS = 0, EPI_RELUMASK = 1, EPI_ADD = 2, EPI_NONE = 3 };
+
+struct Conv64Args {
+    const float* x;     // [B,64,T] primary input
+    const float* x2;    // [B,64,T] second input (PRO_BNBWD)
+    const float* wp;    // packed weights [KW][64 in][64 out]
+    const float* pa;    // prologue per-channel a  (BNRELU: scale, BNBWD: A, ADDVEC: vec[B,64])
+    const float* pb;    // prologue per-channel b  (BNRELU: shift, BNBWD: B)
+    const float* pc;    // prologue per-channel c  (BNBWD: C)
+    const float* bias;  // [64] (EPI_BIAS)
+    const float* e1;    // [B,64,T] epilogue tensor (RELUMASK: pre-BN activation, ADD: addend)
+    const float* ea;    // [64] epilogue scale (RELUMASK)
+    const float* eb;    // [64] epilogue shift (RELUMASK)
+    float* y;           // [B,64,T]
+    float* stats;       // [gridDim.x][2][64] partial sums or nullptr
+    int B, T;
+};
+
+template <int PRO>
+__device__ __forceinline__ float pro_apply(float v, float v2, float ca, float cb, float cc) {
+    if (PRO == PRO_BNRELU) return fmaxf(fmaf(v, ca, cb), 0.f);
+    if (PRO == PRO_ADDVEC) return v + ca;
+    if (PRO == PRO_BNBWD) return fmaf(ca, v, fmaf(cc, v2, cb));
+    return v;
+}
+
+template <int KW, int NT, int PRO, int EPI, bool STATS>
+__global__ __launch_bounds__(256) void conv64_kernel(Conv64Args a) {
+    constexpr int PAD = KW / 2;
+    constexpr int XS = NT + 8;            // LDS row stride; main part starts at column 4 (16-B aligned)
+    constexpr int NTW = NT / 4;           // time columns per wave
+    constexpr int NN = NTW / 32;          // 32-wide N tiles per wave
+    constexpr int QR = NT / 4;            // float4 per row
+    constexpr int NV = 64 * QR / 256;     // float4 per thread per staged tensor
+    constexpr int HTOT = 64 * 2 * PAD;    // halo elements per tile
+    constexpr int HN = (HTOT + 255) / 256;
+    constexpr bool TWO = (PRO == PRO_BNBWD);
+    constexpr bool E1 = (EPI == EPI_RELUMASK || EPI == EPI_ADD);
+
+    extern __shared__ __align__(16) float smem[];
+    float* Ws = smem;                     // [KW*64][64]
+    float* Xs = smem + KW * 4096;         // [64][XS]
+    float* Cs = Xs + 64 * XS;             // [6][64] per-channel constants: pa pb pc bias ea eb
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const int T = a.T;
+    const int tilesPerClip = (T + NT - 1) / NT;
+    const int ntiles = a.B * tilesPerClip;
+
+    float4 st[NV];
+    float4 st2[TWO ? NV : 1];
+    float hl[HN], hl2[TWO ? HN : 1];
+
+    auto load_tile = [&](int tile) {
+        const int b = tile / tilesPerClip, t0 = (tile - b * tilesPerClip) * NT;
+        const float* xb = a.x + (size_t)b * 64 * T;
+        const float* xb2 = TWO ? a.x2 + (size_t)b * 64 * T : nullptr;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int idx = tid + i * 256, c = idx / QR, q = idx % QR, t = t0 + 4 * q;
+            if (t < T) {
+                st[i] = *reinterpret_cast<const float4*>(xb + (size_t)c * T + t);
+                if (TWO) st2[i] = *reinterpret_cast<const float4*>(xb2 + (size_t)c * T + t);
+            } else {
+                st[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (TWO) st2[i] = st[i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < HN; ++i) {
+            const int idx = tid + i * 256;
+            hl[i] = 0.f;
+            if (TWO) hl2[i] = 0.f;
+            if (idx < HTOT) {
+                const int c = idx / (2 * PAD), h = idx % (2 * PAD);
+                const int t = (h < PAD) ? t0 - PAD + h : t0 + NT + (h - PAD);
+                if (t >= 0 && t < T) {
+                    hl[i] = xb[(size_t)c * T + t];
+                    if (TWO) hl2[i] = xb2[(size_t)c * T + t];
+                }
+            }
+        }
+    };
+    auto write_tile = [&](int tile) {
+        const int b = tile / tilesPerClip, t0 = (tile - b * tilesPerClip) * NT;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int idx = tid + i * 256, c = idx / QR, q = idx % QR, t = t0 + 4 * q;
+            float4 v = st[i];
+            if (PRO != PRO_NONE) {
+                const float ca = (PRO == PRO_ADDVEC) ? a.pa[b * 64 + c] : Cs[c];
+                const float cb = Cs[64 + c], cc = Cs[128 + c];
+                const float4 w = TWO ? st2[i] : v;
+                if (t < T) {
+                    v.x = pro_apply<PRO>(v.x, w.x, ca, cb, cc);
+                    v.y = pro_apply<PRO>(v.y, w.y, ca, cb, cc);
+                    v.z = pro_apply<PRO>(v.z, w.z, ca, cb, cc);
+                    v.w = pro_apply<PRO>(v.w, w.w, ca, cb, cc);
+                }
+            }
+            *reinterpret_cast<float4*>(Xs + c * XS + 4 + 4 * q) = v;
+        }
+#pragma unroll
+        for (int i = 0; i < HN; ++i) {
+            const int idx = tid + i * 256;
+            if (idx < HTOT) {
+                const int c = idx / (2 * PAD), h = idx % (2 * PAD);
+                const int t = (h < PAD) ? t0 - PAD + h : t0 + NT + (h - PAD);
+                float v = hl[i];
+                if (PRO != PRO_NONE && t >= 0 && t < T) {
+                    const float ca = (PRO == PRO_ADDVEC) ? a.pa[b * 64 + c] : Cs[c];
+                    v = pro_apply<PRO>(v, TWO ? hl2[i] : v, ca, Cs[64 + c], Cs[128 + c]);
+                }
+                Xs[c * XS + ((h < PAD) ? 4 - PAD + h : 4 + NT + (h - PAD))] = v;
+            }
+        }
+    };
+
+    int tile = blockIdx.x;
+    if (tile < ntiles) load_tile(tile);
+    // resident operands: packed weights + per-channel constants
+    for (int i = tid; i < KW * 1024; i += 256)
+        reinterpret_cast<float4*>(Ws)[i] = reinterpret_cast<const float4*>(a.wp)[i];
+    if (tid < 64) {
+        Cs[tid] = (PRO == PRO_BNRELU || PRO == PRO_BNBWD) ? a.pa[tid] : 0.f;
+        Cs[64 + tid] = (PRO == PRO_BNRELU || PRO == PRO_BNBWD) ? a.pb[tid] : 0.f;
+        Cs[128 + tid] = (PRO == PRO_BNBWD) ? a.pc[tid] : 0.f;
+        Cs[192 + tid] = (EPI == EPI_BIAS && a.bias) ? a.bias[tid] : 0.f;
+        Cs[256 + tid] = (EPI == EPI_RELUMASK) ? a.ea[tid] : 0.f;
+        Cs[320 + tid] = (EPI == EPI_RELUMASK) ? a.eb[tid] : 0.f;
+    }
+    __syncthreads();
+    if (tile < ntiles) write_tile(tile);
+    __syncthreads();
+
+    float s1[STATS ? 32 : 1], s2[STATS ? 32 : 1];
+    if (STATS) {
+#pragma unroll
+        for (int j = 0; j < 32; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+    }
+
+    while (tile < ntiles) {
+        const int next = tile + gridDim.x;
+        if (next < ntiles) load_tile(next);           // in flight while the matrix cores work
+
+        const int b = tile / tilesPerClip, t0 = (tile - b * tilesPerClip) * NT;
+        float e1r[E1 ? 2 * NN * 16 : 1];
+        if (E1) {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NN; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int co = mt * 32 + mfma_row(r, half), t = t0 + wave * NTW + nt * 32 + l31;
+                        e1r[(mt * NN + nt) * 16 + r] = (t < T) ? a.e1[((size_t)b * 64 + co) * T + t] : 0.f;
+                    }
+        }
+
+        f32x16 acc[2][NN];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NN; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+        const float* xcol = Xs + half * XS + (4 - PAD) + wave * NTW + l31;
+        const float* wrow = Ws + half * 64 + l31;
+#pragma unroll 1
+        for (int tap = 0; tap < KW; ++tap) {
+#pragma unroll 8
+            for (int cp = 0; cp < 32; ++cp) {
+                const float* wk = wrow + (tap * 64 + 2 * cp) * 64;
+                const float* xk = xcol + (2 * cp) * XS + tap;
+                const float a0 = wk[0], a1 = wk[32];
+                float bv[NN];
+#pragma unroll
+                for (int nt = 0; nt < NN; ++nt) bv[nt] = xk[nt * 32];
+#pragma unroll
+                for (int nt = 0; nt < NN; ++nt) {
+                    acc[0][nt] = mfma32(a0, bv[nt], acc[0][nt]);
+                    acc[1][nt] = mfma32(a1, bv[nt], acc[1][nt]);
+                }
+            }
+        }
+
+        // epilogue straight from the accumulators
+        float* yb = a.y + (size_t)b * 64 * T;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NN; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = mt * 32 + mfma_row(r, half), t = t0 + wave * NTW + nt * 32 + l31;
+                    float v = acc[mt][nt][r];
+                    float q = 0.f;
+                    if (EPI == EPI_BIAS) v += Cs[192 + co];
+                    if (EPI == EPI_RELUMASK) {
+                        q = e1r[(mt * NN + nt) * 16 + r];
+                        v = (fmaf(q, Cs[256 + co], Cs[320 + co]) > 0.f) ? v : 0.f;
+                    }
+                    if (EPI == EPI_ADD) v += e1r[(mt * NN + nt) * 16 + r];
+                    if (t < T) {
+                        yb[(size_t)co * T + t] = v;
+                        if (STATS) {
+                            s1[mt * 16 + r] += v;
+                            s2[mt * 16 + r] += (EPI == EPI_RELUMASK) ? v * q : v * v;
+                        }
+                    }
+                }
+
+        __syncthreads();                              // every wave is done with Xs
+        if (next < ntiles) write_tile(next);
+        __syncthreads();
+        tile = next;
+    }
+
+    if (STATS) {
+        float* red = Xs;                              // [4 waves][2][64]
+#pragma unroll
+        for (int j = 0; j < 32; ++j) { s1[j] = half_wave_sum(s1[j]); s2[j] = half_wave_sum(s2[j]); }
+        if (l31 == 0) {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = mt * 32 + mfma_row(r, half);
+                    red[wave * 128 + co] = s1[mt * 16 + r];
+                    red[wave * 128 + 64 + co] = s2[mt * 16 + r];
+                }
+        }
+        __syncthreads();
+        if (tid < 128)
+            a.stats[(size_t)blockIdx.x * 128 + tid] = red[tid] + red[128 + tid] + red[256 + tid] + red[384 + tid];
+    }
+}
+
+template <int KW, int NT, int PRO, int EPI, bool STATS>
+int launch_conv64(const Conv64Args& a, hipStream_t stream) {
+    constexpr size_t lds = (size_t)(KW * 4096 + 64 * (NT + 8) + 6 * 64) * sizeof(float);
+    static bool attr_done = false;
+    auto kern = conv64_kernel<KW, NT, PRO, EPI, STATS>;
+    if (!attr_done) {
+        WM_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    const int ntiles = a.B * ((a.T + NT - 1) / NT);
+    const int grid = ntiles < kNumCU ? ntiles : kNumCU;
+    if (STATS && grid < kNumCU)
+        WM_TRY(hipMemsetAsync(a.stats, 0, sizeof(float) * 128 * kNumCU, stream));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, a);
+    WM_CHECK_LAUNCH();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight packing: parameter layout -> [tap][in][out] GEMM-A image (runs every step: Adam updates
+// the parameters in place, so the image is rebuilt from the live tensors; 12-28 K elements).
+//   mode 0  conv   forward : wp[tap][ci][co] = w[co][ci][tap]
+//   mode 1  conv   dgrad   : wp[tap][co][ci] = w[co][ci][KW-1-tap]
+//   mode 2  convT  forward : wp[tap][ci][co] = w[ci][co][KW-1-tap]      (w is [in][out][k])
+//   mode 3  convT  dgrad   : wp[tap][co][ci] = w[ci][co][tap]
+// ---------------------------------------------------------------------------------------------
+__global__ void pack_w64_kernel(const float* __restrict__ w, float* __restrict__ wp, int KW, int mode) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= KW * 4096) return;
+    const int tap = i / 4096, in = (i / 64) % 64, out = i % 64;
+    int src;
+    if (mode == 0) src = (out * 64 + in) * KW + tap;
+    else if (mode == 1) src = (in * 64 + out) * KW + (KW - 1 - tap);
+    else if (mode == 2) src = (in * 64 + out) * KW + (KW - 1 - tap);
+    else src = (out * 64 + in) * KW + tap;
+    wp[i] = w[src];
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight gradient:  G[tap][out][in] = sum_{b,t} g[b,out,t] * xin[b,in,t+tap-PAD]   (+ bias grad)
+// as a GEMM with the (b,t) axis as the contraction (K of the MFMA = 2 time steps).
+// Each workgroup writes one partial slab; wgrad64_reduce sums the slabs in a fixed order
+// (bitwise reproducible, no float atomics) into the parameter-gradient layout.
+// ---------------------------------------------------------------------------------------------
+struct Wgrad64Args {
+    const float* g;  const float* g2;                   // gradient tensor(s) [B,64,T]
+    const float* ga; const float* gb; const float* gc;  // BNBWD constants for g
+    const float* x;                                     // layer input [B,64,T]
+    const float* xa; const float* xb;                   // x prologue constants (BNRELU scale/shift, ADDVEC vec[B,64])
+    float* partial;                                     // [grid][KW*4096 + 64]
+    int B, T;
+};
+
+template <int KW, int GPRO, int XPRO>
+__global__ __launch_bounds__(256) void wgrad64_kernel(Wgrad64Args a) {
+    constexpr int NT = 128, PAD = KW / 2;
+    constexpr int GS = NT + 4, XS = NT + 8;
+    constexpr int QR = NT / 4, NV = 64 * QR / 256;      // 8 float4 per thread per tensor
+    constexpr int HTOT = 64 * 2 * PAD, HN = (HTOT + 255) / 256;
+    constexpr bool TIME_SPLIT = (KW == 3);              // waves split the tile's time range, else the taps
+    constexpr int TL = TIME_SPLIT ? KW : 2;             // taps held per wave
+    constexpr bool GTWO = (GPRO == PRO_BNBWD);
+
+    extern __shared__ __align__(16) float smem[];
+    float* Gs = smem;                 // [64][GS]
+    float* Xs = Gs + 64 * GS;         // [64][XS]
+    float* Cs = Xs + 64 * XS;         // [5][64]: ga gb gc xa xb
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const int T = a.T;
+    const int tilesPerClip = (T + NT - 1) / NT, ntiles = a.B * tilesPerClip;
+
+    float4 sg[NV], sg2[GTWO ? NV : 1], sx[NV];
+    float hx[HN];
+    float bsum[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) bsum[i] = 0.f;
+
+    auto load_tile = [&](int tile) {
+        const int b = tile / tilesPerClip, t0 = (tile - b * tilesPerClip) * NT;
+        const size_t base = (size_t)b * 64 * T;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int idx = tid + i * 256, c = idx / QR, q = idx % QR, t = t0 + 4 * q;
+            if (t < T) {
+                sg[i] = *reinterpret_cast<const float4*>(a.g + base + (size_t)c * T + t);
+                if (GTWO) sg2[i] = *reinterpret_cast<const float4*>(a.g2 + base + (size_t)c * T + t);
+                sx[i] = *reinterpret_cast<const float4*>(a.x + base + (size_t)c * T + t);
+            } else {
+                sg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (GTWO) sg2[i] = sg[i];
+                sx[i] = sg[i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < HN; ++i) {
+            const int idx = tid + i * 256;
+            hx[i] = 0.f;
+            if (idx < HTOT) {
+                const int c = idx / (2 * PAD), h = idx % (2 * PAD);
+                const int t = (h < PAD) ? t0 - PAD + h : t0 + NT + (h - PAD);
+                if (t >= 0 && t < T) hx[i] = a.x[base + (size_t)c * T + t];
+            }
+        }
+    };
+    auto write_tile = [&](int tile) {
+        const int b = tile / tilesPerClip, t0 = (tile - b * tilesPerClip) * NT;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int idx = tid + i * 256, c = idx / QR, q = idx % QR, t = t0 + 4 * q;
+            float4 v = sg[i], u = sx[i];
+            if (t < T) {
+                if (GPRO == PRO_BNBWD) {
+                    const float ca = Cs[c], cb = Cs[64 + c], cc = Cs[128 + c];
+                    const float4 w = sg2[i];
+                    v.x = pro_apply<PRO_BNBWD>(v.x, w.x, ca, cb, cc);
+                    v.y = pro_apply<PRO_BNBWD>(v.y, w.y, ca, cb, cc);
+                    v.z = pro_apply<PRO_BNBWD>(v.z, w.z, ca, cb, cc);
+                    v.w = pro_apply<PRO_BNBWD>(v.w, w.w, ca, cb, cc);
+                }
+                if (XPRO != PRO_NONE) {
+                    const float ca = (XPRO == PRO_ADDVEC) ? a.xa[b * 64 + c] : Cs[192 + c];
+                    const float cb = Cs[256 + c];
+                    u.x = pro_apply<XPRO>(u.x, 0.f, ca, cb, 0.f);
+                    u.y = pro_apply<XPRO>(u.y, 0.f, ca, cb, 0.f);
+                    u.z = pro_apply<XPRO>(u.z, 0.f, ca, cb, 0.f);
+                    u.w = pro_apply<XPRO>(u.w, 0.f, ca, cb, 0.f);
+                }
+                bsum[i] += (v.x + v.y) + (v.z + v.w);
+            }
+            *reinterpret_cast<float4*>(Gs + c * GS + 4 * q) = v;
+            *reinterpret_cast<float4*>(Xs + c * XS + 4 + 4 * q) = u;
+        }
+#pragma unroll
+        for (int i = 0; i < HN; ++i) {
+            const int idx = tid + i * 256;
+            if (idx < HTOT) {
+                const int c = idx / (2 * PAD), h = idx % (2 * PAD);
+                const int t = (h < PAD) ? t0 - PAD + h : t0 + NT + (h - PAD);
+                float v = hx[i];
+                if (XPRO != PRO_NONE && t >= 0 && t < T) {
+                    const float ca = (XPRO == PRO_ADDVEC) ? a.xa[b * 64 + c] : Cs[192 + c];
+                    v = pro_apply<XPRO>(v, 0.f, ca, Cs[256 + c], 0.f);
+                }
+                Xs[c * XS + ((h < PAD) ? 4 - PAD + h : 4 + NT + (h - PAD))] = v;
+            }
+        }
+    };
+
+    int tile = blockIdx.x;
+    if (tile < ntiles) load_tile(tile);
+    if (tid < 64) {
+        Cs[tid] = GTWO ? a.ga[tid] : 0.f;
+        Cs[64 + tid] = GTWO ? a.gb[tid] : 0.f;
+        Cs[128 + tid] = GTWO ? a.gc[tid] : 0.f;
+        Cs[192 + tid] = (XPRO == PRO_BNRELU) ? a.xa[tid] : 0.f;
+        Cs[256 + tid] = (XPRO == PRO_BNRELU) ? a.xb[tid] : 0.f;
+    }
+    __syncthreads();
+    if (tile < ntiles) write_tile(tile);
+    __syncthreads();
+
+    f32x16 acc[TL][2][2];
+#pragma unroll
+    for (int tl = 0; tl < TL; ++tl)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[tl][mt][nt][r] = 0.f;
+
+    const int tbeg = TIME_SPLIT ? wave * (NT / 4) : 0;
+    constexpr int NSTEP = (TIME_SPLIT ? NT / 4 : NT) / 2;
+
+    while (tile < ntiles) {
+        const int next = tile + gridDim.x;
+        if (next < ntiles) load_tile(next);
+        const float* gp = Gs + l31 * GS + tbeg + half;
+        const float* xp = Xs + l31 * XS + (4 - PAD) + tbeg + half;
+#pragma unroll 4
+        for (int s = 0; s < NSTEP; ++s) {
+            const float a0 = gp[2 * s], a1 = gp[32 * GS + 2 * s];
+#pragma unroll
+            for (int tl = 0; tl < TL; ++tl) {
+                const int tap = TIME_SPLIT ? tl : wave + 4 * tl;
+                if (TIME_SPLIT || tap < KW) {
+                    const float b0 = xp[2 * s + tap], b1 = xp[32 * XS + 2 * s + tap];
+                    acc[tl][0][0] = mfma32(a0, b0, acc[tl][0][0]);
+                    acc[tl][0][1] = mfma32(a0, b1, acc[tl][0][1]);
+                    acc[tl][1][0] = mfma32(a1, b0, acc[tl][1][0]);
+                    acc[tl][1][1] = mfma32(a1, b1, acc[tl][1][1]);
+                }
+            }
+        }
+        __syncthreads();
+        if (next < ntiles) write_tile(next);
+        __syncthreads();
+        tile = next;
+    }
+
+    float* out = a.partial + (size_t)blockIdx.x * (KW * 4096 + 64);
+    if (TIME_SPLIT) {
+        // fixed-order reduction of the four waves' slabs through LDS (reuses the tile buffers)
+        float* red = smem;            // KW*4096 floats = 48 KB <= tile buffers (67 KB)
+        for (int w = 0; w < 4; ++w) {
+            if (wave == w) {
+#pragma unroll
+                for (int tl = 0; tl < TL; ++tl)
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                const int o = (tl * 64 + mt * 32 + mfma_row(r, half)) * 64 + nt * 32 + l31;
+                                red[o] = (w == 0) ? acc[tl][mt][nt][r] : red[o] + acc[tl][mt][nt][r];
+                            }
+            }
+            __syncthreads();
+        }
+        for (int i = tid; i < KW * 4096; i += 256) out[i] = red[i];
+    } else {
+#pragma unroll
+        for (int tl = 0; tl < TL; ++tl) {
+            const int tap = wave + 4 * tl;
+            if (tap < KW) {
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            out[(tap * 64 + mt * 32 + mfma_row(r, half)) * 64 + nt * 32 + l31] = acc[tl][mt][nt][r];
+            }
+        }
+    }
+    // bias gradient: rows of this thread are c = idx / QR with idx = tid + i*256 -> (tid>>5) + 8 i;
+    // the 32 lanes of a half-wave share the row.
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const float v = half_wave_sum(bsum[i]);
+        if (l31 == 0) out[KW * 4096 + (tid >> 5) + 8 * i] = v;
+    }
+}
+
+template <int KW, int GPRO, int XPRO>
+int launch_wgrad64(const Wgrad64Args& a, int* grid_out, hipStream_t stream) {
+    constexpr int NT = 128;
+    constexpr size_t lds = (size_t)(64 * (NT + 4) + 64 * (NT + 8) + 5 * 64) * sizeof(float);
+    static bool attr_done = false;
+    auto kern = wgrad64_kernel<KW, GPRO, XPRO>;
+    if (!attr_done) {
+        WM_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    const int ntiles = a.B * ((a.T + NT - 1) / NT);
+    const int grid = ntiles < kNumCU ? ntiles : kNumCU;
+    *grid_out = grid;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, a);
+    WM_CHECK_LAUNCH();
+    return 0;
+}
+
+// dst layout: mode 0 conv  dW[out][in][KW]   <- G[tap][out][in]
+//             mode 1 convT dW[in][out][KW]   <- G[KW-1-k][out][in]
+__global__ void wgrad64_reduce_kernel(const float* __restrict__ partial, int nparts, int KW, int mode,
+                                      float* __restrict__ dw, float* __restrict__ dbias, int accumulate) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int stride = KW * 4096 + 64;
+    if (i >= stride) return;
+    float s = 0.f;
+    for (int p = 0; p < nparts; ++p) s += partial[(size_t)p * stride + i];
+    if (i < KW * 4096) {
+        const int tap = i / 4096, out = (i / 64) % 64, in = i % 64;
+        const int dst = (mode == 0) ? (out * 64 + in) * KW + tap : (in * 64 + out) * KW + (KW - 1 - tap);
+        dw[dst] = accumulate ? dw[dst] + s : s;
+    } else if (dbias) {
+        const int c = i - KW * 4096;
+        dbias[c] = accumulate ? dbias[c] + s : s;
+    }
+}
+
+}  // namespace
+
+// =============================================================================================
+// C ABI
+// =============================================================================================
+extern "C" {
+
+int wm_pack_w64(const float* w, float* wp, int KW, int mode, hipStream_t stream) {
+    if ((KW != 3 && KW != 7) || mode < 0 || mode > 3) return (int)hipErrorInvalidValue;
+    const int n = KW * 4096;
+    hipLaunchKernelGGL(pack_w64_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, w, wp, KW, mode);
+    WM_CHECK_LAUNCH();
+    return 0;
+}
+
+// Generic 64->64 'same' convolution on [B,64,T] (T % 4 == 0).
+//   pro: 0 none | 1 relu(x*pa[c]+pb[c]) | 2 x+pa[b*64+c] | 3 pa[c]*x + pb[c] + pc[c]*x2
+//   epi: 0 +bias | 1 mask by (e1*ea[c]+eb[c] > 0), stats = (sum v, sum v*e1) | 2 +e1 | 3 none
+//   stats (may be NULL; epi 0: (sum y, sum y^2)): [256][2][64] partial sums, reduce with wm_bn_finalize*.
+int wm_conv64(const float* x, const float* x2, const float* wp, const float* pa, const float* pb, const float* pc,
+              const float* bias, const float* e1, const float* ea, const float* eb, float* y, float* stats,
+              int B, int T, int KW, int pro, int epi, hipStream_t stream) {
+    if (B <= 0 || T <= 0 || (T & 3)) return (int)hipErrorInvalidValue;
+    Conv64Args a{x, x2, wp, pa, pb, pc, bias, e1, ea, eb, y, stats, B, T};
+    const bool st = stats != nullptr;
+    if (KW == 3) {
+        if (pro == PRO_NONE && epi == EPI_BIAS)
+            return st ? launch_conv64<3, 256, PRO_NONE, EPI_BIAS, true>(a, stream) : launch_conv64<3, 256, PRO_NONE, EPI_BIAS, false>(a, stream);
+        if (pro == PRO_BNRELU && epi == EPI_BIAS)
+            return st ? launch_conv64<3, 256, PRO_BNRELU, EPI_BIAS, true>(a, stream) : launch_conv64<3, 256, PRO_BNRELU, EPI_BIAS, false>(a, stream);
+        if (pro == PRO_BNBWD && epi == EPI_RELUMASK && st) return launch_conv64<3, 128, PRO_BNBWD, EPI_RELUMASK, true>(a, stream);
+        if (pro == PRO_BNBWD && epi == EPI_ADD && !st) return launch_conv64<3, 128, PRO_BNBWD, EPI_ADD, false>(a, stream);
+        if (pro == PRO_BNBWD && epi == EPI_NONE && !st) return launch_conv64<3, 128, PRO_BNBWD, EPI_NONE, false>(a, stream);
+    } else if (KW == 7 && !st) {
+        if (pro == PRO_ADDVEC && epi == EPI_BIAS) return launch_conv64<7, 128, PRO_ADDVEC, EPI_BIAS, false>(a, stream);
+        if (pro == PRO_NONE && epi == EPI_BIAS) return launch_conv64<7, 128, PRO_NONE, EPI_BIAS, false>(a, stream);
+        if (pro == PRO_NONE && epi == EPI_NONE) return launch_conv64<7, 128, PRO_NONE, EPI_NONE, false>(a, stream);
+    }
+    return (int)hipErrorInvalidValue;
+}
+
+// Weight gradient of a 64->64 convolution.  partial: [256][KW*4096+64] scratch.
+//   gpro: 0 g as is | 3 ga[c]*g + gb[c] + gc[c]*g2     xpro: 0 | 1 relu(x*xa+xb) | 2 x+xa[b*64+c]
+//   layout: 0 Conv1d weight [out][in][KW] | 1 ConvTranspose1d weight [in][out][KW]
+int wm_wgrad64(const float* g, const float* g2, const float* ga, const float* gb, const float* gc,
+               const float* x, const float* xa, const float* xb, float* partial, float* dw, float* dbias,
+               int B, int T, int KW, int gpro, int xpro, int layout, int accumulate, hipStream_t stream) {
+    if (B <= 0 || T <= 0 || (T & 3)) return (int)hipErrorInvalidValue;
+    Wgrad64Args a{g, g2, ga, gb, gc, x, xa, xb, partial, B, T};
+    int grid = 0, rc = (int)hipErrorInvalidValue;
+    if (KW == 3 && gpro == PRO_BNBWD && xpro == PRO_BNRELU) rc = launch_wgrad64<3, PRO_BNBWD, PRO_BNRELU>(a, &grid, stream);
+    else if (KW == 3 && gpro == PRO_BNBWD && xpro == PRO_NONE) rc = launch_wgrad64<3, PRO_BNBWD, PRO_NONE>(a, &grid, stream);
+    else if (KW == 7 && gpro == PRO_NONE && xpro == PRO_ADDVEC) rc = launch_wgrad64<7, PRO_NONE, PRO_ADDVEC>(a, &grid, stream);
+    else if (KW == 7 && gpro == PRO_NONE && xpro == PRO_NONE) rc = launch_wgrad64<7, PRO_NONE, PRO_NONE>(a, &grid, stream);
+    if (rc) return rc;
+    const int n = KW * 4096 + 64;
+    hipLaunchKernelGGL(wgrad64_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, (const float*)partial, grid, KW,
+                       layout, dw, dbias, accumulate);
+    WM_CHECK_LAUNCH();
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,426 @@
+// nn.LSTM(64, 64, batch_first=True), one layer, zero initial state, gate order i,f,g,o
+// (py/main16.py:138,152-154) over T = 16000 dependent steps per clip.
+//
+// Split the MI355X way:
+//   1. wm_lstm_xproj     xp[b,t,:] = W_ih x[b,:,t] + b_ih + b_hh for every t at once -- a GEMM with
+//                        time as M, on the fp32 matrix cores, reading the channel-first encoder
+//                        frame directly (no permute pass).
+//   2. wm_lstm_fwd       the recurrence: ONE 256-thread workgroup per clip, persistent over all T
+//                        steps.  W_hh (256x64 fp32) lives in registers (one gate row per lane), h is
+//                        broadcast through a double-buffered 256-B LDS line, the four gates of a
+//                        hidden unit sit in one wave (lane = gate*16 + unit) and are exchanged with
+//                        bpermutes, so there is exactly one s_barrier per time step.  H = 64 makes
+//                        the recurrent product a 256x64 GEMV per clip: an LDS-broadcast dot product,
+//                        not an MFMA shape.  h is written channel-first [B,64,T] for the decoder.
+//   3. wm_lstm_bwd       BPTT with the same geometry (dh = W_hh^T da as per-wave partial GEMVs, one
+//                        barrier per step); it overwrites the saved gate activations with the
+//                        pre-activation gradients da[b,t,256].
+//   4. wm_lstm_dx / wm_lstm_wgrad   everything that is NOT sequential leaves the recurrence:
+//                        dx = da W_ih, dW_ih = da^T x, dW_hh = da^T h_{t-1}, db = sum da are MFMA GEMMs.
+#include "wm_common.hpp"
+using namespace wm;
+
+namespace {
+
+// ------------------------------------------------------------------------------------ xproj
+// block = (clip, 128-step tile); wave w owns gate columns [64w, 64w+64); D rows = time, cols = gate.
+__global__ __launch_bounds__(256) void lstm_xproj_kernel(const float* __restrict__ x, const float* __restrict__ w_ih,
+                                                         const float* __restrict__ b_ih, const float* __restrict__ b_hh,
+                                                         float* __restrict__ xp, int T) {
+    constexpr int NT = 128, XS = NT + 4;
+    __shared__ __align__(16) float xs[64 * XS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const int tilesPerClip = (T + NT - 1) / NT;
+    const int b = blockIdx.x / tilesPerClip, t0 = (blockIdx.x % tilesPerClip) * NT;
+    const float* xb = x + (size_t)b * 64 * T;
+    for (int i = tid; i < 64 * (NT / 4); i += 256) {
+        const int c = i / (NT / 4), q = i % (NT / 4), t = t0 + 4 * q;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (t < T) v = *reinterpret_cast<const float4*>(xb + (size_t)c * T + t);
+        *reinterpret_cast<float4*>(xs + c * XS + 4 * q) = v;
+    }
+    // B operand (W_ih^T) for this wave's two 32-column tiles: B[k = c][j = n] = w_ih[n][c]
+    float breg[2][32];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int s = 0; s < 32; ++s) breg[nt][s] = w_ih[(wave * 64 + nt * 32 + l31) * 64 + 2 * s + half];
+    float bias[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) bias[nt] = b_ih[wave * 64 + nt * 32 + l31] + b_hh[wave * 64 + nt * 32 + l31];
+    __syncthreads();
+#pragma unroll 1
+    for (int mt = 0; mt < 4; ++mt) {
+        f32x16 acc0, acc1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+        const float* ap = xs + half * XS + mt * 32 + l31;     // A[i = t][k = c] = xs[c][t]
+#pragma unroll
+        for (int s = 0; s < 32; ++s) {
+            const float a = ap[2 * s * XS];
+            acc0 = mfma32(a, breg[0][s], acc0);
+            acc1 = mfma32(a, breg[1][s], acc1);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int t = t0 + mt * 32 + mfma_row(r, half);
+            if (t < T) {
+                float* o = xp + ((size_t)b * T + t) * 256 + wave * 64 + l31;
+                o[0] = acc0[r] + bias[0];
+                o[32] = acc1[r] + bias[1];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------- recurrence fwd
+// sigmoid via v_exp_f32 + v_rcp_f32.  The absolute error of sigma is sigma*(1-sigma)*|z|*O(1e-7)
+// <= 3e-8 for every z (the derivative vanishes where |z| is large), well inside fp32 round-off.
+__device__ __forceinline__ float sigm(float z) { return __builtin_amdgcn_rcpf(1.0f + __expf(-z)); }
+__device__ __forceinline__ float tanh_s(float z) { return fmaf(2.0f, sigm(2.0f * z), -1.0f); }
+// one transcendental pair per lane whatever the gate: tanh(x) = 2*sigmoid(2x) - 1 for the g lanes
+__device__ __forceinline__ float gate_act(float x, bool is_g) {
+    const float s = sigm(is_g ? 2.0f * x : x);
+    return is_g ? fmaf(2.0f, s, -1.0f) : s;
+}
+
+template <bool SAVE>
+__global__ __launch_bounds__(256) void lstm_fwd_kernel(const float* xp, const float* __restrict__ w_hh,
+                                                       float* __restrict__ hout, float* gates,   // gates may alias xp
+                                                       float* __restrict__ cst, int T) {
+    __shared__ __align__(16) float hs[2][64];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q = lane >> 4, ul = lane & 15, u = wave * 16 + ul, n = q * 64 + u;
+    float wr[64];
+#pragma unroll
+    for (int k = 0; k < 64; k += 4) {
+        const float4 v = *reinterpret_cast<const float4*>(w_hh + n * 64 + k);
+        wr[k] = v.x; wr[k + 1] = v.y; wr[k + 2] = v.z; wr[k + 3] = v.w;
+    }
+    if (tid < 128) (&hs[0][0])[tid] = 0.f;
+    float c = 0.f;
+    const float* xpb = xp + (size_t)b * T * 256 + n;
+    float* gb = SAVE ? gates + (size_t)b * T * 256 + n : nullptr;
+    float* cb = SAVE ? cst + (size_t)b * T * 64 + u : nullptr;
+    float* hb = hout + ((size_t)b * 64 + u) * T;
+    const bool is_g = (q == 2);
+
+    float xa[16], xb_[16];
+    auto prefetch = [&](float (&buf)[16], int t0) {
+#pragma unroll
+        for (int s = 0; s < 16; ++s) buf[s] = (t0 + s < T) ? xpb[(size_t)(t0 + s) * 256] : 0.f;
+    };
+    auto run_chunk = [&](const float (&xin)[16], int t0) {
+        float hk[4];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const int t = t0 + s;
+            if (t < T) {                                   // uniform across the workgroup
+                const float4* hp = reinterpret_cast<const float4*>(hs[s & 1]);
+                float a0 = xin[s], a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+                for (int k = 0; k < 16; k += 4) {
+                    const float4 h0 = hp[k], h1 = hp[k + 1], h2 = hp[k + 2], h3 = hp[k + 3];
+                    a0 = fmaf(wr[4 * k + 0], h0.x, a0); a1 = fmaf(wr[4 * k + 1], h0.y, a1);
+                    a2 = fmaf(wr[4 * k + 2], h0.z, a2); a3 = fmaf(wr[4 * k + 3], h0.w, a3);
+                    a0 = fmaf(wr[4 * k + 4], h1.x, a0); a1 = fmaf(wr[4 * k + 5], h1.y, a1);
+                    a2 = fmaf(wr[4 * k + 6], h1.z, a2); a3 = fmaf(wr[4 * k + 7], h1.w, a3);
+                    a0 = fmaf(wr[4 * k + 8], h2.x, a0); a1 = fmaf(wr[4 * k + 9], h2.y, a1);
+                    a2 = fmaf(wr[4 * k + 10], h2.z, a2); a3 = fmaf(wr[4 * k + 11], h2.w, a3);
+                    a0 = fmaf(wr[4 * k + 12], h3.x, a0); a1 = fmaf(wr[4 * k + 13], h3.y, a1);
+                    a2 = fmaf(wr[4 * k + 14], h3.z, a2); a3 = fmaf(wr[4 * k + 15], h3.w, a3);
+                }
+                const float act = gate_act((a0 + a1) + (a2 + a3), is_g);
+                const float gi = __shfl(act, ul), gf = __shfl(act, ul + 16), gg = __shfl(act, ul + 32), go = __shfl(act, ul + 48);
+                c = fmaf(gf, c, gi * gg);
+                const float h = go * tanh_s(c);
+                if (q == 0) hs[(s + 1) & 1][u] = h;
+                if (SAVE) {
+                    gb[(size_t)t * 256] = act;
+                    if (q == 1) cb[(size_t)t * 64] = c;
+                }
+                if (((s >> 2) & 3) == q) hk[s & 3] = h;
+                if ((s & 3) == 3 && (s >> 2) == 3) {
+                    // every lane now holds h for steps t0+4q .. t0+4q+3 of its unit
+                    const int tq = t0 + 4 * q;
+                    if (tq + 3 < T) *reinterpret_cast<float4*>(hb + tq) = make_float4(hk[0], hk[1], hk[2], hk[3]);
+                }
+                __syncthreads();
+            }
+        }
+        // ragged tail (T not a multiple of 16): flush what the last partial chunk produced
+        if (t0 + 16 > T) {
+            const int tq = t0 + 4 * q;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (tq + j < T) hb[tq + j] = hk[j];
+        }
+    };
+
+    prefetch(xa, 0);
+    __syncthreads();
+    for (int t0 = 0; t0 < T; t0 += 32) {
+        prefetch(xb_, t0 + 16);
+        run_chunk(xa, t0);
+        prefetch(xa, t0 + 32);
+        if (t0 + 16 < T) run_chunk(xb_, t0 + 16);
+    }
+}
+
+// ------------------------------------------------------------------------------- recurrence bwd
+// gates: in = saved activations (i,f,g,o), out = pre-activation gradients da  [B,T,256]
+__global__ __launch_bounds__(256) void lstm_bwd_kernel(float* __restrict__ gates, const float* __restrict__ cst,
+                                                       const float* __restrict__ dh_out, const float* __restrict__ w_hh,
+                                                       int T) {
+    __shared__ __align__(16) float das[4][64];      // wave-private da vectors
+    __shared__ __align__(16) float part[2][64][4];  // [buffer][k][wave] partial dh
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q = lane >> 4, ul = lane & 15, u = wave * 16 + ul, n = q * 64 + u;
+    // transposed-product operand: lane = output k, register j = row held by lane j of this wave
+    float wt[64];
+#pragma unroll
+    for (int j = 0; j < 64; ++j) wt[j] = w_hh[((j >> 4) * 64 + wave * 16 + (j & 15)) * 64 + lane];
+    if (tid < 512 / 4) reinterpret_cast<float4*>(&part[0][0][0])[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+    float dc = 0.f;
+    float* gb = gates + (size_t)b * T * 256;
+    const float* cb = cst + (size_t)b * T * 64 + u;
+    const float* dhb = dh_out + ((size_t)b * 64 + u) * T;
+
+    constexpr int CH = 8;
+    struct Buf { float gi[CH], gf[CH], gg[CH], go[CH], cc[CH + 1], dh[CH]; };
+    Buf A, Bf;
+    // chunk covers steps t1-CH+1 .. t1 (descending); cc[j] = c_{t1-CH+j} so cc[CH] = c_{t1}
+    auto prefetch = [&](Buf& f, int t1) {
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            const int t = t1 - CH + 1 + j;
+            const bool ok = (t >= 0);
+            const float* gp = gb + (size_t)(ok ? t : 0) * 256 + u;
+            f.gi[j] = ok ? gp[0] : 0.f; f.gf[j] = ok ? gp[64] : 0.f; f.gg[j] = ok ? gp[128] : 0.f; f.go[j] = ok ? gp[192] : 0.f;
+            f.dh[j] = ok ? dhb[t] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j <= CH; ++j) {
+            const int t = t1 - CH + j;
+            f.cc[j] = (t >= 0) ? cb[(size_t)t * 64] : 0.f;
+        }
+    };
+    int pb = 0;   // partial buffer parity
+    auto run_chunk = [&](const Buf& f, int t1) {
+#pragma unroll
+        for (int jj = 0; jj < CH; ++jj) {
+            const int j = CH - 1 - jj, t = t1 - jj;
+            if (t >= 0) {
+                const float4 p = *reinterpret_cast<const float4*>(&part[pb][u][0]);
+                const float dht = f.dh[j] + ((p.x + p.y) + (p.z + p.w));
+                const float gi = f.gi[j], gf = f.gf[j], gg = f.gg[j], go = f.go[j];
+                const float tc = tanh_s(f.cc[j + 1]);
+                const float dct = fmaf(dht * go, 1.f - tc * tc, dc);
+                float da;
+                if (q == 0) da = dct * gg * gi * (1.f - gi);
+                else if (q == 1) da = dct * f.cc[j] * gf * (1.f - gf);
+                else if (q == 2) da = dct * gi * (1.f - gg * gg);
+                else da = dht * tc * go * (1.f - go);
+                dc = dct * gf;
+                gb[(size_t)t * 256 + n] = da;
+                das[wave][lane] = da;                       // same wave reads it back: no barrier needed
+                __builtin_amdgcn_wave_barrier();
+                const float4* dp = reinterpret_cast<const float4*>(das[wave]);
+                float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const float4 d = dp[k];
+                    a0 = fmaf(wt[4 * k], d.x, a0); a1 = fmaf(wt[4 * k + 1], d.y, a1);
+                    a2 = fmaf(wt[4 * k + 2], d.z, a2); a3 = fmaf(wt[4 * k + 3], d.w, a3);
+                }
+                part[pb ^ 1][lane][wave] = (a0 + a1) + (a2 + a3);
+                pb ^= 1;
+                __syncthreads();
+            }
+        }
+    };
+    prefetch(A, T - 1);
+    __syncthreads();
+    for (int t1 = T - 1; t1 >= 0; t1 -= 2 * CH) {
+        prefetch(Bf, t1 - CH);
+        run_chunk(A, t1);
+        prefetch(A, t1 - 2 * CH);
+        run_chunk(Bf, t1 - CH);
+    }
+}
+
+// ------------------------------------------------------------------------------------ dx GEMM
+// dx[b,c,t] = sum_n da[b,t,n] w_ih[n][c] ;  block = (clip, 64-step tile); wave = (c half, t half)
+__global__ __launch_bounds__(256) void lstm_dx_kernel(const float* __restrict__ da, const float* __restrict__ w_ih,
+                                                      float* __restrict__ dx, int T) {
+    constexpr int NT = 64, DS = 257;
+    extern __shared__ __align__(16) float smem[];
+    float* ws = smem;               // [256][64]  A[i = c][k = n] = w_ih[n][c]
+    float* ds = smem + 256 * 64;    // [NT][DS]   B[k = n][j = t] = da[t][n]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const int tilesPerClip = (T + NT - 1) / NT;
+    const int b = blockIdx.x / tilesPerClip, t0 = (blockIdx.x % tilesPerClip) * NT;
+    for (int i = tid; i < 256 * 16; i += 256) reinterpret_cast<float4*>(ws)[i] = reinterpret_cast<const float4*>(w_ih)[i];
+    const float* dab = da + ((size_t)b * T + t0) * 256;
+    for (int i = tid; i < NT * 64; i += 256) {
+        const int tt = i >> 6, q4 = i & 63;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (t0 + tt < T) v = reinterpret_cast<const float4*>(dab)[i];
+        float* d = ds + tt * DS + 4 * q4;
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+    __syncthreads();
+    const int mt = wave & 1, nt = wave >> 1;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const float* ap = ws + half * 64 + mt * 32 + l31;
+    const float* bp = ds + (nt * 32 + l31) * DS + half;
+#pragma unroll 8
+    for (int s = 0; s < 128; ++s) acc = mfma32(ap[2 * s * 64], bp[2 * s], acc);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int c = mt * 32 + mfma_row(r, half), t = t0 + nt * 32 + l31;
+        if (t < T) dx[((size_t)b * 64 + c) * T + t] = acc[r];
+    }
+}
+
+// ---------------------------------------------------------------------------------- wgrad GEMM
+// G[n][j] = sum_{b,t} da[b,t,n] * z[b,j,t],  z = [x (64 rows) ; h shifted by one step (64 rows)]
+// persistent blocks over (clip, 64-step) tiles; partial[block][256*128 + 256 (bias)]
+__global__ __launch_bounds__(256) void lstm_wgrad_kernel(const float* __restrict__ da, const float* __restrict__ x,
+                                                         const float* __restrict__ h, float* __restrict__ partial,
+                                                         int B, int T) {
+    constexpr int NT = 64, ZS = NT + 1;
+    extern __shared__ __align__(16) float smem[];
+    float* ds = smem;                // [NT][256]
+    float* zs = smem + NT * 256;     // [128][ZS]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const int tilesPerClip = (T + NT - 1) / NT, ntiles = B * tilesPerClip;
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+    float bsum = 0.f;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int b = tile / tilesPerClip, t0 = (tile % tilesPerClip) * NT;
+        __syncthreads();
+        const float* dab = da + ((size_t)b * T + t0) * 256;
+        for (int i = tid; i < NT * 64; i += 256) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (t0 + (i >> 6) < T) v = reinterpret_cast<const float4*>(dab)[i];
+            reinterpret_cast<float4*>(ds)[i] = v;
+        }
+        for (int i = tid; i < 128 * NT; i += 256) {
+            const int j = i / NT, tt = i % NT, t = t0 + tt;
+            float v = 0.f;
+            if (t < T) {
+                if (j < 64) v = x[((size_t)b * 64 + j) * T + t];
+                else if (t >= 1) v = h[((size_t)b * 64 + (j - 64)) * T + t - 1];
+            }
+            zs[j * ZS + tt] = v;
+        }
+        __syncthreads();
+        // A[i = n][k = t] = ds[t][n] ; B[k = t][j] = zs[j][t]
+        const float* ap = ds + half * 256 + wave * 64 + l31;
+        const float* bp = zs + l31 * ZS + half;
+#pragma unroll 4
+        for (int s = 0; s < NT / 2; ++s) {
+            const float a0 = ap[2 * s * 256], a1 = ap[2 * s * 256 + 32];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const float bv = bp[nt * 32 * ZS + 2 * s];
+                acc[0][nt] = mfma32(a0, bv, acc[0][nt]);
+                acc[1][nt] = mfma32(a1, bv, acc[1][nt]);
+            }
+        }
+        for (int tt = 0; tt < NT; ++tt) bsum += ds[tt * 256 + tid];
+    }
+    float* out = partial + (size_t)blockIdx.x * (256 * 128 + 256);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                out[(wave * 64 + mt * 32 + mfma_row(r, half)) * 128 + nt * 32 + l31] = acc[mt][nt][r];
+    out[256 * 128 + tid] = bsum;
+}
+
+__global__ void lstm_wgrad_reduce_kernel(const float* __restrict__ partial, int nparts, float* dw_ih, float* dw_hh,
+                                         float* db_ih, float* db_hh, int accumulate) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    constexpr int stride = 256 * 128 + 256;
+    if (i >= stride) return;
+    float s = 0.f;
+    for (int p = 0; p < nparts; ++p) s += partial[(size_t)p * stride + i];
+    if (i < 256 * 128) {
+        const int n = i >> 7, j = i & 127;
+        float* dst = (j < 64) ? dw_ih + n * 64 + j : dw_hh + n * 64 + (j - 64);
+        *dst = accumulate ? *dst + s : s;
+    } else {
+        const int n = i - 256 * 128;
+        db_ih[n] = accumulate ? db_ih[n] + s : s;
+        db_hh[n] = accumulate ? db_hh[n] + s : s;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+// xp [B,T,256] = x[B,64,T]^T W_ih^T + b_ih + b_hh
+int wm_lstm_xproj(const float* x, const float* w_ih, const float* b_ih, const float* b_hh, float* xp, int B, int T,
+                  hipStream_t stream) {
+    if (T & 3) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(lstm_xproj_kernel, dim3(B * ((T + 127) / 128)), dim3(256), 0, stream, x, w_ih, b_ih, b_hh, xp, T);
+    WM_CHECK_LAUNCH();
+    return 0;
+}
+
+// hout [B,64,T]; gates [B,T,256] and cst [B,T,64] are written only when both are non-NULL (training).
+int wm_lstm_fwd(const float* xp, const float* w_hh, float* hout, float* gates, float* cst, int B, int T, hipStream_t stream) {
+    if (T & 3) return (int)hipErrorInvalidValue;
+    if (gates && cst) hipLaunchKernelGGL(lstm_fwd_kernel<true>, dim3(B), dim3(256), 0, stream, xp, w_hh, hout, gates, cst, T);
+    else hipLaunchKernelGGL(lstm_fwd_kernel<false>, dim3(B), dim3(256), 0, stream, xp, w_hh, hout, gates, cst, T);
+    WM_CHECK_LAUNCH();
+    return 0;
+}
+
+// gates: saved activations in, da out.  dh_out [B,64,T] = gradient w.r.t. hout.
+int wm_lstm_bwd(float* gates, const float* cst, const float* dh_out, const float* w_hh, int B, int T, hipStream_t stream) {
+    hipLaunchKernelGGL(lstm_bwd_kernel, dim3(B), dim3(256), 0, stream, gates, cst, dh_out, w_hh, T);
+    WM_CHECK_LAUNCH();
+    return 0;
+}
+
+int wm_lstm_dx(const float* da, const float* w_ih, float* dx, int B, int T, hipStream_t stream) {
+    constexpr size_t lds = (size_t)(256 * 64 + 64 * 257) * sizeof(float);
+    static bool done = false;
+    if (!done) { WM_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_dx_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); done = true; }
+    hipLaunchKernelGGL(lstm_dx_kernel, dim3(B * ((T + 63) / 64)), dim3(256), lds, stream, da, w_ih, dx, T);
+    WM_CHECK_LAUNCH();
+    return 0;
+}
+
+// partial: >= 256 * (256*128 + 256) floats
+int wm_lstm_wgrad(const float* da, const float* x, const float* h, float* partial, float* dw_ih, float* dw_hh,
+                  float* db_ih, float* db_hh, int B, int T, int accumulate, hipStream_t stream) {
+    constexpr size_t lds = (size_t)(64 * 256 + 128 * 65) * sizeof(float);
+    static bool done = false;
+    if (!done) { WM_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); done = true; }
+    const int ntiles = B * ((T + 63) / 64);
+    const int grid = ntiles < kNumCU ? ntiles : kNumCU;
+    hipLaunchKernelGGL(lstm_wgrad_kernel, dim3(grid), dim3(256), lds, stream, da, x, h, partial, B, T);
+    WM_CHECK_LAUNCH();
+    constexpr int n = 256 * 128 + 256;
+    hipLaunchKernelGGL(lstm_wgrad_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, (const float*)partial, grid,
+                       dw_ih, dw_hh, db_ih, db_hh, accumulate);
+    WM_CHECK_LAUNCH();
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,385 @@
+// The thin ends of the two networks (py/main16.py):
+//   stem   Conv1d(1,64,7,padding=3)   Generator.encoder[0] :134 / Detector.model[0] :177
+//   head1  Conv1d(64,1,1)             Generator.decoder[2] :146
+//   head17 Conv1d(64,1+bits,1)        Detector.model[3]    :180, written directly in the
+//                                     (B,T,1+bits) layout Detector.forward returns (:186)
+// These are HBM-bound (one 64-channel frame in or out per sample, a handful of FLOPs per
+// byte) so they are plain VALU kernels with 16-B coalesced frame accesses; only the tiny
+// one-channel side goes through LDS.
+#include "wm_common.hpp"
+using namespace wm;
+
+namespace {
+
+// ------------------------------------------------------------------------------- stem forward
+// block = (clip, 1024-sample tile); thread = 4 consecutive samples; loop over the 64 filters.
+__global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__ s, const float* __restrict__ w,
+                                                       const float* __restrict__ bias, float* __restrict__ y, int T) {
+    __shared__ float ss[1024 + 8];
+    __shared__ float ws[64 * 8];
+    const int tilesPerClip = (T + 1023) / 1024;
+    const int b = blockIdx.x / tilesPerClip, t0 = (blockIdx.x % tilesPerClip) * 1024;
+    const float* sb = s + (size_t)b * T;
+    for (int i = threadIdx.x; i < 1024 + 6; i += 256) {
+        const int t = t0 - 3 + i;
+        ss[i] = (t >= 0 && t < T) ? sb[t] : 0.f;
+    }
+    for (int i = threadIdx.x; i < 512; i += 256) {
+        const int co = i >> 3, j = i & 7;
+        ws[i] = (j < 7) ? w[co * 7 + j] : bias[co];
+    }
+    __syncthreads();
+    const int t = t0 + 4 * threadIdx.x;
+    if (t >= T) return;
+    float v[10];
+#pragma unroll
+    for (int i = 0; i < 10; ++i) v[i] = ss[4 * threadIdx.x + i];
+    float* yb = y + (size_t)b * 64 * T + t;
+#pragma unroll 4
+    for (int co = 0; co < 64; ++co) {
+        const float* wc = ws + co * 8;
+        float4 o = make_float4(wc[7], wc[7], wc[7], wc[7]);
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+            const float wj = wc[j];
+            o.x = fmaf(wj, v[j], o.x);
+            o.y = fmaf(wj, v[j + 1], o.y);
+            o.z = fmaf(wj, v[j + 2], o.z);
+            o.w = fmaf(wj, v[j + 3], o.w);
+        }
+        *reinterpret_cast<float4*>(yb + (size_t)co * T) = o;
+    }
+}
+
+// ------------------------------------------------------------------------------ stem backward
+// g [B,64,T]; persistent blocks over (clip, 256-sample) tiles.
+//   ds[b,t]   = sum_{co,j} g[co,t-j+3] w[co][j]          (only if ds != nullptr)
+//   dw[co][j] = sum_{b,t} g[co,t] s[t+j-3] ; db[co] = sum g[co,t]   -> partial[block][64*8]
+__global__ __launch_bounds__(256) void stem_bwd_kernel(const float* __restrict__ g, const float* __restrict__ s,
+                                                       const float* __restrict__ w, float* __restrict__ ds,
+                                                       float* __restrict__ partial, int B, int T) {
+    constexpr int NT = 256, GS = NT + 8;             // g tile row: [3 halo][256][3 halo] at offset 1
+    extern __shared__ __align__(16) float smem[];
+    float* gs = smem;                                // [64][GS]
+    float* ss = gs + 64 * GS;                        // [NT + 8]
+    float* ws = ss + NT + 8;                         // [64][8]
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 512; i += 256) ws[i] = ((i & 7) < 7) ? w[(i >> 3) * 7 + (i & 7)] : 0.f;
+    const int tilesPerClip = (T + NT - 1) / NT, ntiles = B * tilesPerClip;
+    // reduction roles: thread -> (co = tid >> 2, jg = tid & 3) handles taps jg and jg + 4 (tap 7 == bias)
+    const int rco = tid >> 2, rj = tid & 3;
+    float accA = 0.f, accB = 0.f;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int b = tile / tilesPerClip, t0 = (tile % tilesPerClip) * NT;
+        const float* gb = g + (size_t)b * 64 * T;
+        __syncthreads();
+        for (int i = tid; i < 64 * (NT / 4); i += 256) {
+            const int c = i / (NT / 4), q = i % (NT / 4), t = t0 + 4 * q;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (t < T) v = *reinterpret_cast<const float4*>(gb + (size_t)c * T + t);
+            *reinterpret_cast<float4*>(gs + c * GS + 4 + 4 * q) = v;
+        }
+        for (int i = tid; i < 64 * 6; i += 256) {
+            const int c = i / 6, h = i % 6;
+            const int t = (h < 3) ? t0 - 3 + h : t0 + NT + (h - 3);
+            gs[c * GS + ((h < 3) ? 1 + h : 4 + NT + (h - 3))] = (t >= 0 && t < T) ? gb[(size_t)c * T + t] : 0.f;
+        }
+        for (int i = tid; i < NT + 6; i += 256) {
+            const int t = t0 - 3 + i;
+            ss[i] = (t >= 0 && t < T) ? s[(size_t)b * T + t] : 0.f;
+        }
+        __syncthreads();
+        if (ds) {
+            const int t = t0 + tid;
+            if (t < T) {
+                float acc = 0.f;
+                const float* gp = gs + 4 + tid + 3;          // g[co][t + 3 - j]
+#pragma unroll 4
+                for (int co = 0; co < 64; ++co) {
+#pragma unroll
+                    for (int j = 0; j < 7; ++j) acc = fmaf(gp[co * GS - j], ws[co * 8 + j], acc);
+                }
+                ds[(size_t)b * T + t] = acc;
+            }
+        }
+        {
+            const float* gp = gs + rco * GS + 4;
+            const float* sA = ss + rj;                        // s[t + j - 3] -> ss[t - t0 + j]
+            float a0 = 0.f, a1 = 0.f;
+            if (rj < 3) {
+#pragma unroll 8
+                for (int t = 0; t < NT; ++t) { const float gv = gp[t]; a0 = fmaf(gv, sA[t], a0); a1 = fmaf(gv, sA[t + 4], a1); }
+            } else {
+#pragma unroll 8
+                for (int t = 0; t < NT; ++t) { const float gv = gp[t]; a0 = fmaf(gv, sA[t], a0); a1 += gv; }
+            }
+            accA += a0; accB += a1;
+        }
+    }
+    float* out = partial + (size_t)blockIdx.x * 512;
+    out[rco * 8 + rj] = accA;
+    out[rco * 8 + rj + 4] = accB;
+}
+
+// out[i] (+)= sum_p partial[p*stride + i],  i < count
+__global__ void reduce_partials_kernel(const float* __restrict__ partial, int nparts, int stride, int count,
+                                       float* __restrict__ out, int accumulate) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    float s = 0.f;
+    for (int p = 0; p < nparts; ++p) s += partial[(size_t)p * stride + i];
+    out[i] = accumulate ? out[i] + s : s;
+}
+// stem partial [nparts][64][8] -> dw[64][7], db[64]
+__global__ void stem_reduce_kernel(const float* __restrict__ partial, int nparts, float* dw, float* db, int accumulate) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 512) return;
+    float s = 0.f;
+    for (int p = 0; p < nparts; ++p) s += partial[(size_t)p * 512 + i];
+    const int co = i >> 3, j = i & 7;
+    float* dst = (j < 7) ? dw + co * 7 + j : db + co;
+    *dst = accumulate ? *dst + s : s;
+}
+
+// ------------------------------------------------------------------------------------ head1
+__global__ __launch_bounds__(256) void head1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, float* __restrict__ y, int T4,
+                                                        int total4) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= total4) return;
+    const int b = i / T4, q = i % T4;
+    const float4* xb = reinterpret_cast<const float4*>(x) + (size_t)b * 64 * T4 + q;
+    const float b0 = bias[0];
+    float4 o = make_float4(b0, b0, b0, b0);
+#pragma unroll 8
+    for (int c = 0; c < 64; ++c) {
+        const float4 v = xb[(size_t)c * T4];
+        const float wc = w[c];
+        o.x = fmaf(wc, v.x, o.x); o.y = fmaf(wc, v.y, o.y); o.z = fmaf(wc, v.z, o.z); o.w = fmaf(wc, v.w, o.w);
+    }
+    reinterpret_cast<float4*>(y)[i] = o;
+}
+
+// dx[c,t] = w[c] g[t];  dw[c] = sum g[t] x[c,t];  db = sum g   -> partial[block][65]
+__global__ __launch_bounds__(256) void head1_bwd_kernel(const float* __restrict__ g, const float* __restrict__ x,
+                                                        const float* __restrict__ w, float* __restrict__ dx,
+                                                        float* __restrict__ partial, int T4, int total4) {
+    __shared__ float red[4][65];
+    float acc[65];
+#pragma unroll
+    for (int c = 0; c < 65; ++c) acc[c] = 0.f;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total4; i += gridDim.x * 256) {
+        const int b = i / T4, q = i % T4;
+        const float4 gv = reinterpret_cast<const float4*>(g)[i];
+        const size_t base = (size_t)b * 64 * T4 + q;
+        acc[64] += (gv.x + gv.y) + (gv.z + gv.w);
+#pragma unroll
+        for (int c = 0; c < 64; ++c) {
+            const float4 v = reinterpret_cast<const float4*>(x)[base + (size_t)c * T4];
+            acc[c] += fmaf(gv.x, v.x, gv.y * v.y) + fmaf(gv.z, v.z, gv.w * v.w);
+            const float wc = w[c];
+            reinterpret_cast<float4*>(dx)[base + (size_t)c * T4] = make_float4(wc * gv.x, wc * gv.y, wc * gv.z, wc * gv.w);
+        }
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int c = 0; c < 65; ++c) {
+        const float v = wave_sum(acc[c]);
+        if (lane == 0) red[wv][c] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 65)
+        partial[(size_t)blockIdx.x * 65 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+// ------------------------------------------------------------------------------------ head17
+// logits[b,t,o] = bias[o] + sum_c w[o][c] x[b,c,t]     NO = 1 + message_bits (<= 17)
+template <int NO>
+__global__ __launch_bounds__(256) void headN_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, float* __restrict__ y, int T) {
+    __shared__ float ws[NO * 64 + NO];
+    __shared__ float os[256 * NO];
+    const int tilesPerClip = (T + 255) / 256;
+    const int b = blockIdx.x / tilesPerClip, t0 = (blockIdx.x % tilesPerClip) * 256;
+    for (int i = threadIdx.x; i < NO * 64 + NO; i += 256) ws[i] = (i < NO * 64) ? w[i] : bias[i - NO * 64];
+    __syncthreads();
+    const int t = t0 + threadIdx.x;
+    float acc[NO];
+#pragma unroll
+    for (int o = 0; o < NO; ++o) acc[o] = ws[NO * 64 + o];
+    if (t < T) {
+        const float* xb = x + (size_t)b * 64 * T + t;
+#pragma unroll 4
+        for (int c = 0; c < 64; ++c) {
+            const float v = xb[(size_t)c * T];
+#pragma unroll
+            for (int o = 0; o < NO; ++o) acc[o] = fmaf(ws[o * 64 + c], v, acc[o]);
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < NO; ++o) os[threadIdx.x * NO + o] = acc[o];
+    __syncthreads();
+    const int nvalid = min(256, T - t0) * NO;
+    float* yb = y + ((size_t)b * T + t0) * NO;
+    for (int i = threadIdx.x; i < nvalid; i += 256) yb[i] = os[i];
+}
+
+// g [B,T,NO] -> dx[b,c,t] = sum_o w[o][c] g[b,t,o];  dw[o][c] = sum g[b,t,o] x[b,c,t];  db[o] = sum g
+// partial[block][NO*64 + NO]
+template <int NO>
+__global__ __launch_bounds__(256) void headN_bwd_kernel(const float* __restrict__ g, const float* __restrict__ x,
+                                                        const float* __restrict__ w, float* __restrict__ dx,
+                                                        float* __restrict__ partial, int B, int T) {
+    constexpr int XS = 257;
+    extern __shared__ __align__(16) float smem[];
+    float* xs = smem;                  // [64][XS]
+    float* gsm = xs + 64 * XS;         // [256][NO]
+    float* ws = gsm + 256 * NO;        // [NO][64]
+    const int tid = threadIdx.x;
+    for (int i = tid; i < NO * 64; i += 256) ws[i] = w[i];
+    const int tilesPerClip = (T + 255) / 256, ntiles = B * tilesPerClip;
+    // reduction roles: c = tid & 63, og = tid >> 6 -> outputs o = og, og+4, ... (< NO); thread 0..NO-1 also own db[o]
+    constexpr int NR = (NO + 3) / 4;
+    float accw[NR];
+#pragma unroll
+    for (int k = 0; k < NR; ++k) accw[k] = 0.f;
+    float accb = 0.f;
+    const int rc = tid & 63, rog = tid >> 6;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int b = tile / tilesPerClip, t0 = (tile % tilesPerClip) * 256;
+        const int nt = min(256, T - t0);
+        __syncthreads();
+        const float* gb = g + ((size_t)b * T + t0) * NO;
+        for (int i = tid; i < 256 * NO; i += 256) gsm[i] = (i < nt * NO) ? gb[i] : 0.f;
+        const float* xb = x + (size_t)b * 64 * T + t0;
+        for (int i = tid; i < 64 * 256; i += 256) {
+            const int c = i >> 8, tt = i & 255;
+            xs[c * XS + tt] = (tt < nt) ? xb[(size_t)c * T + tt] : 0.f;
+        }
+        __syncthreads();
+        if (tid < nt) {
+            float gv[NO];
+#pragma unroll
+            for (int o = 0; o < NO; ++o) gv[o] = gsm[tid * NO + o];
+            float* dxb = dx + (size_t)b * 64 * T + t0 + tid;
+#pragma unroll 4
+            for (int c = 0; c < 64; ++c) {
+                float a = 0.f;
+#pragma unroll
+                for (int o = 0; o < NO; ++o) a = fmaf(ws[o * 64 + c], gv[o], a);
+                dxb[(size_t)c * T] = a;
+            }
+        }
+        {
+            const float* xr = xs + rc * XS;
+            for (int tt = 0; tt < 256; ++tt) {
+                const float xv = xr[tt];
+#pragma unroll
+                for (int k = 0; k < NR; ++k) {
+                    const int o = rog + 4 * k;
+                    if (o < NO) accw[k] = fmaf(gsm[tt * NO + o], xv, accw[k]);
+                }
+            }
+            if (tid < NO)
+                for (int tt = 0; tt < 256; ++tt) accb += gsm[tt * NO + tid];
+        }
+    }
+    float* out = partial + (size_t)blockIdx.x * (NO * 64 + NO);
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+        const int o = rog + 4 * k;
+        if (o < NO) out[o * 64 + rc] = accw[k];
+    }
+    if (tid < NO) out[NO * 64 + tid] = accb;
+}
+
+}  // namespace
+
+extern "C" {
+
+int wm_stem_fwd(const float* s, const float* w, const float* bias, float* y, int B, int T, hipStream_t stream) {
+    if (T & 3) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(stem_fwd_kernel, dim3(B * ((T + 1023) / 1024)), dim3(256), 0, stream, s, w, bias, y, T);
+    WM_CHECK_LAUNCH();
+    return 0;
+}
+
+// partial: >= 256*512 floats of scratch.  ds may be NULL (Generator stem: the clip is data).
+int wm_stem_bwd(const float* g, const float* s, const float* w, float* ds, float* partial, float* dw, float* db, int B,
+                int T, int accumulate, hipStream_t stream) {
+    if (T & 3) return (int)hipErrorInvalidValue;
+    constexpr size_t lds = (size_t)(64 * 264 + 264 + 512) * sizeof(float);
+    static bool attr_done = false;
+    if (!attr_done) {
+        WM_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(stem_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    const int ntiles = B * ((T + 255) / 256);
+    const int grid = ntiles < kNumCU ? ntiles : kNumCU;
+    hipLaunchKernelGGL(stem_bwd_kernel, dim3(grid), dim3(256), lds, stream, g, s, w, ds, partial, B, T);
+    WM_CHECK_LAUNCH();
+    hipLaunchKernelGGL(stem_reduce_kernel, dim3(2), dim3(256), 0, stream, (const float*)partial, grid, dw, db, accumulate);
+    WM_CHECK_LAUNCH();
+    return 0;
+}
+
+int wm_head1_fwd(const float* x, const float* w, const float* bias, float* y, int B, int T, hipStream_t stream) {
+    if (T & 3) return (int)hipErrorInvalidValue;
+    const int total4 = B * (T / 4);
+    hipLaunchKernelGGL(head1_fwd_kernel, dim3((total4 + 255) / 256), dim3(256), 0, stream, x, w, bias, y, T / 4, total4);
+    WM_CHECK_LAUNCH();
+    return 0;
+}
+
+// partial: >= 1024*65 floats.  dwb: [65] = dw[64] followed by db[1] (two separate tensors on the host side).
+int wm_head1_bwd(const float* g, const float* x, const float* w, float* dx, float* partial, float* dw, float* db, int B,
+                 int T, int accumulate, hipStream_t stream) {
+    if (T & 3) return (int)hipErrorInvalidValue;
+    const int total4 = B * (T / 4);
+    int grid = (total4 + 255) / 256;
+    if (grid > 1024) grid = 1024;
+    hipLaunchKernelGGL(head1_bwd_kernel, dim3(grid), dim3(256), 0, stream, g, x, w, dx, partial, T / 4, total4);
+    WM_CHECK_LAUNCH();
+    // partial [grid][65]: first 64 -> dw, last -> db
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(64), 0, stream, (const float*)partial, grid, 65, 64, dw, accumulate);
+    WM_CHECK_LAUNCH();
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(64), 0, stream, (const float*)partial + 64, grid, 65, 1, db, accumulate);
+    WM_CHECK_LAUNCH();
+    return 0;
+}
+
+int wm_headN_fwd(const float* x, const float* w, const float* bias, float* y, int B, int T, int NO, hipStream_t stream) {
+    const int grid = B * ((T + 255) / 256);
+    if (NO == 17) hipLaunchKernelGGL(headN_fwd_kernel<17>, dim3(grid), dim3(256), 0, stream, x, w, bias, y, T);
+    else if (NO == 1) hipLaunchKernelGGL(headN_fwd_kernel<1>, dim3(grid), dim3(256), 0, stream, x, w, bias, y, T);
+    else return (int)hipErrorInvalidValue;
+    WM_CHECK_LAUNCH();
+    return 0;
+}
+
+// partial: >= 256*(NO*64+NO) floats
+int wm_headN_bwd(const float* g, const float* x, const float* w, float* dx, float* partial, float* dw, float* db, int B,
+                 int T, int NO, int accumulate, hipStream_t stream) {
+    const int ntiles = B * ((T + 255) / 256);
+    const int grid = ntiles < kNumCU ? ntiles : kNumCU;
+    const size_t lds = (size_t)(64 * 257 + 256 * NO + NO * 64) * sizeof(float);
+    if (NO == 17) {
+        static bool done = false;
+        if (!done) { WM_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(headN_bwd_kernel<17>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); done = true; }
+        hipLaunchKernelGGL(headN_bwd_kernel<17>, dim3(grid), dim3(256), lds, stream, g, x, w, dx, partial, B, T);
+    } else if (NO == 1) {
+        static bool done = false;
+        if (!done) { WM_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(headN_bwd_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); done = true; }
+        hipLaunchKernelGGL(headN_bwd_kernel<1>, dim3(grid), dim3(256), lds, stream, g, x, w, dx, partial, B, T);
+    } else return (int)hipErrorInvalidValue;
+    WM_CHECK_LAUNCH();
+    const int n = NO * 64 + NO;
+    // partial rows are [NO*64 weights | NO biases]; reduce the two pieces with matching row stride
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((NO * 64 + 255) / 256), dim3(256), 0, stream, (const float*)partial, grid, n, NO * 64, dw, accumulate);
+    WM_CHECK_LAUNCH();
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(64), 0, stream, (const float*)partial + NO * 64, grid, n, NO, db, accumulate);
+    WM_CHECK_LAUNCH();
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,71 @@
+// Shared device helpers for the gfx950 (MI355X / CDNA4) watermark kernels.
+// Wave = 64 lanes everywhere; no portability layer on purpose.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define WM_CHECK_LAUNCH() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)
+#define WM_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return (int)e_; } while (0)
+
+namespace wm {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kWave = 64;
+constexpr int kNumCU = 256;          // MI355X: 8 XCD x 32 CU
+
+// D(32x32) += A(32x2) * B(2x32), exact fp32 (v_mfma_f32_32x32x2_f32).
+// lane l supplies A[i = l&31][k = l>>5] and B[k = l>>5][j = l&31];
+// D: col = l&31, row = (r&3) + 8*(r>>2) + 4*(l>>5) for register r in [0,16).
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ int mfma_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+// sum over the 32 lanes that share (lane>>5)
+__device__ __forceinline__ float half_wave_sum(float v) {
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// block-wide sum for blocks of NW waves; result valid in every thread. scratch: >= NW floats of LDS.
+template <int NW>
+__device__ __forceinline__ float block_sum(float v, float* scratch) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) scratch[w] = v;
+    __syncthreads();
+    float r = 0.f;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) r += scratch[i];
+    return r;
+}
+template <int NW>
+__device__ __forceinline__ double block_sum_d(double v, double* scratch) {
+    v = wave_sum_d(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) scratch[w] = v;
+    __syncthreads();
+    double r = 0.0;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) r += scratch[i];
+    return r;
+}
+
+__device__ __forceinline__ float sigmoidf_acc(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+}  // namespace wm

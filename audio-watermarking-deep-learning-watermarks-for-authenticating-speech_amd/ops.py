@@ -1,0 +1,417 @@
+"""torch.autograd.Function wrappers over the C ABI (include/wm_hip.h).
+
+PyTorch is used here for device memory, streams and the autograd tape only; every
+arithmetic step of the hot path is a launch into libwm_hip.so.  Each Function mirrors one
+block of the reference graph (py/main16.py:112-186, :53-81, :192-217).
+"""
+from __future__ import annotations
+
+import torch
+
+from ._lib import lib
+
+NCU = 256            # workgroups the persistent kernels are sized for (MI355X CU count)
+BN_EPS = 1e-5        # nn.BatchNorm1d defaults (py/main16.py:117,120)
+BN_MOMENTUM = 0.1
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _chk(t: torch.Tensor, name: str, ndim: int | None = None, dtype=torch.float32) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a tensor, got {type(t).__name__}")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: the watermark hot path runs on the GPU only (got a {t.device} tensor); "
+                           "there is no CPU fallback")
+    if t.dtype != dtype:
+        raise ValueError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+    if ndim is not None and t.dim() != ndim:
+        raise ValueError(f"{name}: expected {ndim} dims, got shape {tuple(t.shape)}")
+    return t.contiguous()
+
+
+def _frames(x: torch.Tensor, name: str, ch: int) -> torch.Tensor:
+    x = _chk(x, name, 3)
+    if x.shape[1] != ch:
+        raise ValueError(f"{name}: expected {ch} channels, got shape {tuple(x.shape)}")
+    if x.shape[2] % 4 != 0:
+        raise ValueError(f"{name}: clip length must be a multiple of 4 samples, got {x.shape[2]}")
+    return x
+
+
+def _f32(*shape, device):
+    return torch.empty(shape, dtype=torch.float32, device=device)
+
+
+def pack_w64(w: torch.Tensor, kw: int, mode: int) -> torch.Tensor:
+    wp = _f32(kw * 4096, device=w.device)
+    lib.wm_pack_w64(_p(w), _p(wp), kw, mode, _stream())
+    return wp
+
+
+# ------------------------------------------------------------------------------------------ ResBlock
+class ResBlockFn(torch.autograd.Function):
+    """relu(x + BN2(conv2(relu(BN1(conv1(x))))))  -- ResBlock.forward, py/main16.py:124-125."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, g1, be1, w2, b2, g2, be2, rm1, rv1, nbt1, rm2, rv2, nbt2, training):
+        x = _frames(x, "ResBlock input", 64)
+        B, _, T = x.shape
+        dev, st = x.device, _stream()
+        wp1, wp2 = pack_w64(w1, 3, 0), pack_w64(w2, 3, 0)
+        y1, y2, out = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+        cst = _f32(8, 64, device=dev)       # sc1 sh1 mean1 is1 sc2 sh2 mean2 is2
+        sc1, sh1, mu1, is1, sc2, sh2, mu2, is2 = cst.unbind(0)
+        if training:
+            stats = _f32(NCU * 128, device=dev)
+            lib.wm_conv64(_p(x), None, _p(wp1), None, None, None, _p(b1), None, None, None, _p(y1), _p(stats), B, T, 3, 0, 0, st)
+            lib.wm_bn_finalize(_p(stats), NCU, float(B * T), _p(g1), _p(be1), _p(rm1), _p(rv1), _p(nbt1), BN_MOMENTUM, BN_EPS,
+                               _p(sc1), _p(sh1), _p(mu1), _p(is1), st)
+            lib.wm_conv64(_p(y1), None, _p(wp2), _p(sc1), _p(sh1), None, _p(b2), None, None, None, _p(y2), _p(stats), B, T, 3, 1, 0, st)
+            lib.wm_bn_finalize(_p(stats), NCU, float(B * T), _p(g2), _p(be2), _p(rm2), _p(rv2), _p(nbt2), BN_MOMENTUM, BN_EPS,
+                               _p(sc2), _p(sh2), _p(mu2), _p(is2), st)
+        else:
+            lib.wm_bn_eval_scale_shift(_p(g1), _p(be1), _p(rm1), _p(rv1), BN_EPS, _p(sc1), _p(sh1), st)
+            lib.wm_bn_eval_scale_shift(_p(g2), _p(be2), _p(rm2), _p(rv2), BN_EPS, _p(sc2), _p(sh2), st)
+            lib.wm_conv64(_p(x), None, _p(wp1), None, None, None, _p(b1), None, None, None, _p(y1), None, B, T, 3, 0, 0, st)
+            lib.wm_conv64(_p(y1), None, _p(wp2), _p(sc1), _p(sh1), None, _p(b2), None, None, None, _p(y2), None, B, T, 3, 1, 0, st)
+            # saved (mean, invstd) for an eval-mode backward = running statistics
+            mu1.copy_(rm1); is1.copy_(torch.rsqrt(rv1 + BN_EPS)); mu2.copy_(rm2); is2.copy_(torch.rsqrt(rv2 + BN_EPS))
+        lib.wm_bn_add_relu(_p(x), _p(y2), _p(sc2), _p(sh2), _p(out), B, T, st)
+        ctx.training = bool(training)
+        ctx.save_for_backward(x, y1, y2, out, cst, w1, w2, g1, g2)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        x, y1, y2, out, cst, w1, w2, g1, g2 = ctx.saved_tensors
+        sc1, sh1, mu1, is1, sc2, sh2, mu2, is2 = cst.unbind(0)
+        g_out = g_out.contiguous()
+        B, _, T = x.shape
+        dev, st = x.device, _stream()
+        ev = 0 if ctx.training else 1
+        n = float(B * T)
+        dz2 = torch.empty_like(x)
+        part = _f32(max(B, 1) * 128, device=dev)
+        lib.wm_relu_bwd_reduce(_p(g_out), _p(out), _p(y2), _p(dz2), _p(part), B, T, st)
+        k2 = _f32(3, 64, device=dev)
+        dg2, dbe2 = _f32(64, device=dev), _f32(64, device=dev)
+        lib.wm_bn_bwd_finalize(_p(part), B, n, _p(g2), _p(mu2), _p(is2), _p(k2[0]), _p(k2[1]), _p(k2[2]), _p(dg2), _p(dbe2), 0, ev, st)
+        # conv2: data gradient (+ ReLU mask + BN1-backward reductions in the epilogue) and weight gradient
+        wp2d = pack_w64(w2, 3, 1)
+        dz1 = torch.empty_like(x)
+        stats = _f32(NCU * 128, device=dev)
+        lib.wm_conv64(_p(dz2), _p(y2), _p(wp2d), _p(k2[0]), _p(k2[1]), _p(k2[2]), None, _p(y1), _p(sc1), _p(sh1), _p(dz1), _p(stats),
+                      B, T, 3, 3, 1, st)
+        wpart = _f32(NCU * (3 * 4096 + 64), device=dev)
+        dw2, db2 = torch.empty_like(w2), _f32(64, device=dev)
+        lib.wm_wgrad64(_p(dz2), _p(y2), _p(k2[0]), _p(k2[1]), _p(k2[2]), _p(y1), _p(sc1), _p(sh1), _p(wpart), _p(dw2), _p(db2),
+                       B, T, 3, 3, 1, 0, 0, st)
+        k1 = _f32(3, 64, device=dev)
+        dg1, dbe1 = _f32(64, device=dev), _f32(64, device=dev)
+        lib.wm_bn_bwd_finalize(_p(stats), NCU, n, _p(g1), _p(mu1), _p(is1), _p(k1[0]), _p(k1[1]), _p(k1[2]), _p(dg1), _p(dbe1), 0, ev, st)
+        # conv1: data gradient + residual path, weight gradient
+        wp1d = pack_w64(w1, 3, 1)
+        dx = torch.empty_like(x)
+        lib.wm_conv64(_p(dz1), _p(y1), _p(wp1d), _p(k1[0]), _p(k1[1]), _p(k1[2]), None, _p(dz2), None, None, _p(dx), None, B, T, 3, 3, 2, st)
+        dw1, db1 = torch.empty_like(w1), _f32(64, device=dev)
+        lib.wm_wgrad64(_p(dz1), _p(y1), _p(k1[0]), _p(k1[1]), _p(k1[2]), _p(x), None, None, _p(wpart), _p(dw1), _p(db1),
+                       B, T, 3, 3, 0, 0, 0, st)
+        return dx, dw1, db1, dg1, dbe1, dw2, db2, dg2, dbe2, None, None, None, None, None, None, None
+
+
+# ------------------------------------------------------------------------------------------ stem / heads
+class StemFn(torch.autograd.Function):
+    """Conv1d(1, 64, 7, padding=3) -- py/main16.py:134 / :177."""
+
+    @staticmethod
+    def forward(ctx, s, w, b):
+        s = _frames(s, "clip batch", 1)
+        B, _, T = s.shape
+        y = _f32(B, 64, T, device=s.device)
+        lib.wm_stem_fwd(_p(s), _p(w), _p(b), _p(y), B, T, _stream())
+        ctx.save_for_backward(s, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        s, w = ctx.saved_tensors
+        g = g.contiguous()
+        B, _, T = s.shape
+        ds = torch.empty_like(s) if ctx.needs_input_grad[0] else None
+        part = _f32(NCU * 512, device=s.device)
+        dw, db = torch.empty_like(w), _f32(64, device=s.device)
+        lib.wm_stem_bwd(_p(g), _p(s), _p(w), _p(ds), _p(part), _p(dw), _p(db), B, T, 0, _stream())
+        return ds, dw, db
+
+
+class Head1Fn(torch.autograd.Function):
+    """Conv1d(64, 1, 1) -- Generator.decoder[2], py/main16.py:146."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        x = _frames(x, "head input", 64)
+        B, _, T = x.shape
+        y = _f32(B, 1, T, device=x.device)
+        lib.wm_head1_fwd(_p(x), _p(w), _p(b), _p(y), B, T, _stream())
+        ctx.save_for_backward(x, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        g = g.contiguous()
+        B, _, T = x.shape
+        dx = torch.empty_like(x)
+        part = _f32(1024 * 65, device=x.device)
+        dw, db = torch.empty_like(w), _f32(1, device=x.device)
+        lib.wm_head1_bwd(_p(g), _p(x), _p(w), _p(dx), _p(part), _p(dw), _p(db), B, T, 0, _stream())
+        return dx, dw, db
+
+
+class HeadNFn(torch.autograd.Function):
+    """Conv1d(64, 1+bits, 1) followed by permute(0,2,1) -- Detector, py/main16.py:180,186.
+    Returns a contiguous (B, T, 1+bits) tensor (the reference returns a view of the same shape)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        x = _frames(x, "head input", 64)
+        B, _, T = x.shape
+        NO = w.shape[0]
+        if NO not in (1, 17):
+            raise ValueError(f"Detector head: 1+message_bits must be 1 or 17, got {NO}")
+        y = _f32(B, T, NO, device=x.device)
+        lib.wm_headN_fwd(_p(x), _p(w), _p(b), _p(y), B, T, NO, _stream())
+        ctx.save_for_backward(x, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        g = g.contiguous()
+        B, _, T = x.shape
+        NO = w.shape[0]
+        dx = torch.empty_like(x)
+        part = _f32(NCU * (NO * 64 + NO), device=x.device)
+        dw, db = torch.empty_like(w), _f32(NO, device=x.device)
+        lib.wm_headN_bwd(_p(g), _p(x), _p(w), _p(dx), _p(part), _p(dw), _p(db), B, T, NO, 0, _stream())
+        return dx, dw, db
+
+
+# ------------------------------------------------------------------------------------------ LSTM
+class LSTMFn(torch.autograd.Function):
+    """nn.LSTM(64,64,batch_first=True) on channel-first frames: (B,64,T) -> (B,64,T); the two permutes of
+    py/main16.py:152,154 are folded into the kernels' addressing."""
+
+    @staticmethod
+    def forward(ctx, x, w_ih, w_hh, b_ih, b_hh):
+        x = _frames(x, "LSTM input", 64)
+        B, _, T = x.shape
+        dev, st = x.device, _stream()
+        need_grad = any(ctx.needs_input_grad)
+        xp = _f32(B, T, 256, device=dev)
+        lib.wm_lstm_xproj(_p(x), _p(w_ih), _p(b_ih), _p(b_hh), _p(xp), B, T, st)
+        h = torch.empty_like(x)
+        if need_grad:
+            gates, cst = xp, _f32(B, T, 64, device=dev)     # activations overwrite the projections in place
+            lib.wm_lstm_fwd(_p(xp), _p(w_hh), _p(h), _p(gates), _p(cst), B, T, st)
+            ctx.save_for_backward(x, h, gates, cst, w_ih, w_hh)
+        else:
+            lib.wm_lstm_fwd(_p(xp), _p(w_hh), _p(h), None, None, B, T, st)
+        return h
+
+    @staticmethod
+    def backward(ctx, dh):
+        x, h, gates, cst, w_ih, w_hh = ctx.saved_tensors
+        dh = dh.contiguous()
+        B, _, T = x.shape
+        dev, st = x.device, _stream()
+        lib.wm_lstm_bwd(_p(gates), _p(cst), _p(dh), _p(w_hh), B, T, st)          # gates now holds da
+        dx = torch.empty_like(x)
+        lib.wm_lstm_dx(_p(gates), _p(w_ih), _p(dx), B, T, st)
+        part = _f32(NCU * (256 * 128 + 256), device=dev)
+        dwi, dwh = torch.empty_like(w_ih), torch.empty_like(w_hh)
+        dbi, dbh = _f32(256, device=dev), _f32(256, device=dev)
+        lib.wm_lstm_wgrad(_p(gates), _p(x), _p(h), _p(part), _p(dwi), _p(dwh), _p(dbi), _p(dbh), B, T, 0, st)
+        return dx, dwi, dwh, dbi, dbh
+
+
+# ------------------------------------------------------------------------------------------ embedding + convT
+class EmbedFn(torch.autograd.Function):
+    """nn.Embedding lookup, py/main16.py:158 (dense gradient like the reference's sparse=False table)."""
+
+    @staticmethod
+    def forward(ctx, table, message):
+        table = _chk(table, "embedding.weight", 2)
+        message = _chk(message, "message", 1, torch.int64)
+        B = message.shape[0]
+        vec = _f32(B, 64, device=table.device)
+        lib.wm_embed_gather(_p(table), _p(message), _p(vec), B, table.shape[0], None, _stream())
+        ctx.save_for_backward(message)
+        ctx.nrows = table.shape[0]
+        return vec
+
+    @staticmethod
+    def backward(ctx, dvec):
+        (message,) = ctx.saved_tensors
+        dtable = torch.zeros(ctx.nrows, 64, dtype=torch.float32, device=dvec.device)
+        lib.wm_embed_scatter_add(_p(dtable), _p(message), _p(dvec.contiguous()), message.shape[0], ctx.nrows, _stream())
+        return dtable, None
+
+
+class ConvT7Fn(torch.autograd.Function):
+    """ConvTranspose1d(64,64,7,padding=3) applied to x + emb[:, :, None]  (py/main16.py:144,156-161);
+    `vec` (B,64) is the looked-up embedding row or None."""
+
+    @staticmethod
+    def forward(ctx, x, vec, w, b):
+        x = _frames(x, "decoder input", 64)
+        B, _, T = x.shape
+        wp = pack_w64(w, 7, 2)
+        y = torch.empty_like(x)
+        pro = 2 if vec is not None else 0
+        lib.wm_conv64(_p(x), None, _p(wp), _p(vec), None, None, _p(b), None, None, None, _p(y), None, B, T, 7, pro, 0, _stream())
+        ctx.has_vec = vec is not None
+        ctx.save_for_backward(x, w, vec if vec is not None else x.new_empty(0))
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w, vec = ctx.saved_tensors
+        vec = vec if ctx.has_vec else None
+        g = g.contiguous()
+        B, _, T = x.shape
+        dev, st = x.device, _stream()
+        wpd = pack_w64(w, 7, 3)
+        dx = torch.empty_like(x)
+        lib.wm_conv64(_p(g), None, _p(wpd), None, None, None, None, None, None, None, _p(dx), None, B, T, 7, 0, 3, st)
+        part = _f32(NCU * (7 * 4096 + 64), device=dev)
+        dw, db = torch.empty_like(w), _f32(64, device=dev)
+        lib.wm_wgrad64(_p(g), None, None, None, None, _p(x), _p(vec), None, _p(part), _p(dw), _p(db), B, T, 7, 0,
+                       2 if vec is not None else 0, 1, 0, st)
+        dvec = None
+        if vec is not None and ctx.needs_input_grad[1]:
+            dvec = _f32(B, 64, device=dev)
+            lib.wm_rowsum(_p(dx), _p(dvec), B * 64, T, st)
+        return dx, dvec, dw, db
+
+
+# ------------------------------------------------------------------------------------------ delta post-processing
+class PostprocFn(torch.autograd.Function):
+    """stages bit0 fir_lowpass | bit1 clamp_peak | bit2 limit_rms, fused (py/main16.py:53-72, :245-247)."""
+
+    @staticmethod
+    def forward(ctx, delta, taps, thr, max_rms, eps, stages):
+        delta = _frames(delta, "delta", 1)
+        B, _, T = delta.shape
+        dev = delta.device
+        out = torch.empty_like(delta)
+        need = ctx.needs_input_grad[0]
+        f = torch.empty_like(delta) if need else None
+        stats = _f32(B, 2, device=dev)
+        lib.wm_postproc_fwd(_p(delta), _p(taps), taps.numel(), thr, max_rms, eps, stages, _p(f), _p(out), _p(stats), B, T, _stream())
+        if need:
+            ctx.save_for_backward(f, stats, taps)
+        ctx.cfg = (thr, max_rms, stages)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        f, stats, taps = ctx.saved_tensors
+        thr, max_rms, stages = ctx.cfg
+        g = g.contiguous()
+        B, _, T = f.shape
+        d = torch.empty_like(f)
+        lib.wm_postproc_bwd(_p(g), _p(f), _p(stats), _p(taps), taps.numel(), thr, max_rms, stages, _p(d), B, T, _stream())
+        return d, None, None, None, None, None
+
+
+# ------------------------------------------------------------------------------------------ losses
+class _SpectralLossFn(torch.autograd.Function):
+    """Shared shape of the three STFT losses: the kernel returns the loss AND d loss / d signal, the tape
+    only scales the cached gradient by the incoming scalar."""
+
+    @staticmethod
+    def forward(ctx, kind, clean, sig, tables):
+        sig2 = _chk(sig, "signal", 3)
+        B, _, T = sig2.shape
+        dev, st = sig2.device, _stream()
+        need = ctx.needs_input_grad[2]
+        n_fft, hop = {"mel": (1024, 256), "loud": (2048, 512), "hf": (512, 128)}[kind]
+        F = 1 + T // hop
+        loss = _f32(1, device=dev)
+        part = _f32(B * F, device=dev)
+        gfr = _f32(B * F * n_fft, device=dev) if need else None
+        dsig = torch.empty_like(sig2) if need else None
+        if kind == "mel":
+            c2 = _chk(clean, "clean", 3)
+            fb, klo, khi, mlo = tables
+            lib.wm_mel_loss(_p(c2), _p(sig2), _p(fb), _p(klo), _p(khi), _p(mlo), _p(gfr), _p(part), _p(loss), _p(dsig), B, T, st)
+        elif kind == "loud":
+            c2 = _chk(clean, "clean", 3)
+            lib.wm_loud_loss(_p(c2), _p(sig2), 0.01, _p(gfr), _p(part), _p(loss), _p(dsig), B, T, st)
+        else:
+            lib.wm_hf_penalty(_p(sig2), int(tables), _p(gfr), _p(part), _p(loss), _p(dsig), B, T, st)
+        if need:
+            ctx.save_for_backward(dsig)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (dsig,) = ctx.saved_tensors
+        return None, None, dsig * g, None
+
+
+class BCEFn(torch.autograd.Function):
+    """loc_loss and bce of py/main16.py:252-264 from one pass over the (2B,T,1+bits) logits."""
+
+    @staticmethod
+    def forward(ctx, logits, message):
+        logits = _chk(logits, "logits", 3)
+        message = _chk(message, "message", 1, torch.int64)
+        R, T, NO = logits.shape
+        B = message.shape[0]
+        if R != 2 * B:
+            raise ValueError(f"logits must hold [watermarked; clean] = 2*B clips, got {R} for B={B}")
+        dev = logits.device
+        part = _f32(2048, device=dev)
+        out = torch.zeros(2, dtype=torch.float32, device=dev)
+        lib.wm_bce_fwd(_p(logits), _p(message), _p(part), _p(out[0]), _p(out[1]), B, R, T, NO, _stream())
+        ctx.save_for_backward(logits, message)
+        return out[0], out[1]
+
+    @staticmethod
+    def backward(ctx, g_loc, g_bce):
+        logits, message = ctx.saved_tensors
+        R, T, NO = logits.shape
+        gl = g_loc.contiguous().float().reshape(1) if g_loc is not None else torch.zeros(1, device=logits.device)
+        gb = g_bce.contiguous().float().reshape(1) if g_bce is not None else torch.zeros(1, device=logits.device)
+        d = torch.empty_like(logits)
+        lib.wm_bce_bwd(_p(logits), _p(message), _p(gl), _p(gb), _p(d), message.shape[0], R, T, NO, _stream())
+        return d, None
+
+
+class L1Fn(torch.autograd.Function):
+    """F.l1_loss(delta, 0), py/main16.py:266."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = _chk(x, "delta")
+        out = _f32(1, device=x.device)
+        part = _f32(256, device=x.device)
+        lib.wm_l1_fwd(_p(x), _p(part), _p(out), x.numel(), _stream())
+        ctx.save_for_backward(x)
+        return out.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        dx = torch.empty_like(x)
+        lib.wm_l1_bwd(_p(x), _p(g.contiguous().float().reshape(1)), _p(dx), x.numel(), _stream())
+        return dx

@@ -1,0 +1,13 @@
+"""Import shim: ``import awm_amd`` loads the package that lives in the (non-identifier) directory
+``audio-watermarking-deep-learning-watermarks-for-authenticating-speech_amd/``."""
+import importlib.util
+import os
+import sys
+
+_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)),
+                    "audio-watermarking-deep-learning-watermarks-for-authenticating-speech_amd")
+_spec = importlib.util.spec_from_file_location("awm_amd", os.path.join(_dir, "__init__.py"),
+                                               submodule_search_locations=[_dir])
+_mod = importlib.util.module_from_spec(_spec)
+sys.modules["awm_amd"] = _mod
+_spec.loader.exec_module(_mod)

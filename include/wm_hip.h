@@ -1,0 +1,121 @@
+/* wm_hip.h -- C ABI of libwm_hip.so: the MI355X (gfx950) kernels of the watermark embed+detect hot path.
+ *
+ * The reference (py/main16.py) has no FFI: its boundary for this path is the nn.Module call
+ *   Generator.forward(s, message)  py/main16.py:149-162
+ *   Detector.forward(x)            py/main16.py:183-186
+ * plus the free functions / loss modules of py/main16.py:53-81 and :192-217.  Everything those calls reach in
+ * ATen (conv1d, batch_norm, lstm, conv_transpose1d, embedding, stft, ...) is replaced by the stateless launchers
+ * below; the host-side mirror of the nn.Module API lives in the Python package and binds this file with ctypes
+ * (see INTEGRATION.md for the binding a maintainer of the reference would add).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to contiguous fp32 unless stated (message: int64, tables: int32);
+ *   - activations are channel-first frames [B,64,T] exactly as the reference holds them, T % 4 == 0;
+ *   - inputs are borrowed and never written; outputs / scratch are caller-allocated;
+ *   - `stream` is a hipStream_t (pass torch.cuda.current_stream().cuda_stream); launchers enqueue and return,
+ *     they never synchronise, allocate or free (graph-capture safe), and keep no mutable global state;
+ *   - return value: 0 on success, else a hipError_t value (1 = invalid argument / unsupported variant).
+ */
+#ifndef WM_HIP_H
+#define WM_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* wm_stream_t;   /* == hipStream_t */
+
+/* ---- 64->64 convolutions on the fp32 matrix cores -------------------------------------------------------------
+ * replace nn.Conv1d(64,64,3,padding=1) of ResBlock (py/main16.py:116,119) and nn.ConvTranspose1d(64,64,7,padding=3)
+ * (py/main16.py:144), forward and backward.                                                                     */
+
+/* w -> GEMM image wp[KW][64 in][64 out].  mode 0 Conv1d fwd | 1 Conv1d dgrad | 2 ConvTranspose1d fwd | 3 ConvT dgrad */
+int wm_pack_w64(const float* w, float* wp, int KW, int mode, wm_stream_t stream);
+
+/* y = conv_same(pro(x)) then epi.
+ *   pro: 0 x | 1 relu(x*pa[c]+pb[c]) (BatchNorm+ReLU folded into the load, py/main16.py:117-118)
+ *        | 2 x + pa[b*64+c] (message embedding add, py/main16.py:158-159) | 3 pa[c]*x + pb[c] + pc[c]*x2 (BN backward)
+ *   epi: 0 + bias[c] | 1 keep where e1*ea[c]+eb[c] > 0 (ReLU backward) | 2 + e1 (residual gradient) | 3 none
+ *   stats (NULL or [256][2][64]): per-workgroup partial sums for BatchNorm (epi 0: sum y, sum y^2;
+ *   epi 1: sum v, sum v*e1).  Supported (KW,pro,epi): (3,{0,1},0) (3,3,{1,2,3}) (7,{0,2},0) (7,0,3).          */
+int wm_conv64(const float* x, const float* x2, const float* wp, const float* pa, const float* pb, const float* pc,
+              const float* bias, const float* e1, const float* ea, const float* eb, float* y, float* stats,
+              int B, int T, int KW, int pro, int epi, wm_stream_t stream);
+
+/* dW (+)= sum_{b,t} gpro(g)[out,t] * xpro(x)[in,t+tap-KW/2]; dbias (+)= sum gpro(g).  partial: [256][KW*4096+64].
+ *   gpro 0|3, xpro 0|1|2 as above; layout 0: Conv1d weight [out][in][KW], 1: ConvTranspose1d weight [in][out][KW]. */
+int wm_wgrad64(const float* g, const float* g2, const float* ga, const float* gb, const float* gc,
+               const float* x, const float* xa, const float* xb, float* partial, float* dw, float* dbias,
+               int B, int T, int KW, int gpro, int xpro, int layout, int accumulate, wm_stream_t stream);
+
+/* ---- BatchNorm1d(64) glue (py/main16.py:117,120) ----------------------------------------------------------- */
+int wm_bn_finalize(const float* partials, int nparts, double count, const float* gamma, const float* beta,
+                   float* running_mean, float* running_var, long long* num_batches_tracked, float momentum, float eps,
+                   float* scale, float* shift, float* save_mean, float* save_invstd, wm_stream_t stream);
+int wm_bn_eval_scale_shift(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                           float eps, float* scale, float* shift, wm_stream_t stream);
+/* ResBlock tail  out = relu(x + y2*scale + shift)  (py/main16.py:125) and its backward + BN-backward reductions */
+int wm_bn_add_relu(const float* x, const float* y2, const float* scale, const float* shift, float* out, int B, int T,
+                   wm_stream_t stream);
+int wm_relu_bwd_reduce(const float* g, const float* out, const float* y2, float* dz, float* partial, int B, int T,
+                       wm_stream_t stream);
+int wm_bn_bwd_finalize(const float* partials, int nparts, double count, const float* gamma, const float* save_mean,
+                       const float* save_invstd, float* A, float* Bc, float* Cc, float* dgamma, float* dbeta,
+                       int accumulate, int eval_mode, wm_stream_t stream);
+
+/* ---- stem / heads: Conv1d(1,64,7,p=3) :134,:177 ; Conv1d(64,1,1) :146 ; Conv1d(64,1+bits,1) :180 (+permute :186) */
+int wm_stem_fwd(const float* s, const float* w, const float* bias, float* y, int B, int T, wm_stream_t stream);
+int wm_stem_bwd(const float* g, const float* s, const float* w, float* ds, float* partial, float* dw, float* db, int B,
+                int T, int accumulate, wm_stream_t stream);
+int wm_head1_fwd(const float* x, const float* w, const float* bias, float* y, int B, int T, wm_stream_t stream);
+int wm_head1_bwd(const float* g, const float* x, const float* w, float* dx, float* partial, float* dw, float* db, int B,
+                 int T, int accumulate, wm_stream_t stream);
+/* logits written as (B,T,NO) contiguous -- the layout Detector.forward's permuted view exposes */
+int wm_headN_fwd(const float* x, const float* w, const float* bias, float* y, int B, int T, int NO, wm_stream_t stream);
+int wm_headN_bwd(const float* g, const float* x, const float* w, float* dx, float* partial, float* dw, float* db, int B,
+                 int T, int NO, int accumulate, wm_stream_t stream);
+
+/* ---- nn.LSTM(64,64,batch_first=True) :138,:152-154 ---------------------------------------------------------- */
+int wm_lstm_xproj(const float* x, const float* w_ih, const float* b_ih, const float* b_hh, float* xp, int B, int T,
+                  wm_stream_t stream);
+int wm_lstm_fwd(const float* xp, const float* w_hh, float* hout, float* gates, float* cst, int B, int T, wm_stream_t stream);
+int wm_lstm_bwd(float* gates, const float* cst, const float* dh_out, const float* w_hh, int B, int T, wm_stream_t stream);
+int wm_lstm_dx(const float* da, const float* w_ih, float* dx, int B, int T, wm_stream_t stream);
+int wm_lstm_wgrad(const float* da, const float* x, const float* h, float* partial, float* dw_ih, float* dw_hh,
+                  float* db_ih, float* db_hh, int B, int T, int accumulate, wm_stream_t stream);
+
+/* ---- nn.Embedding(2**bits,64) lookup :158 and its dense gradient ------------------------------------------- */
+int wm_embed_gather(const float* table, const long long* message, float* vec, int B, int nrows, int* err, wm_stream_t stream);
+int wm_embed_scatter_add(float* dtable, const long long* message, const float* dvec, int B, int nrows, wm_stream_t stream);
+int wm_rowsum(const float* x, float* out, int rows, int T, wm_stream_t stream);
+
+/* ---- delta post-processing: fir_lowpass :53-64 (bit 0), clamp_peak :66-67 (bit 1), limit_rms :69-72 (bit 2) -- */
+int wm_postproc_fwd(const float* d_in, const float* taps, int ntaps, float thr, float max_rms, float eps, int stages,
+                    float* f_out, float* d_out, float* stats, int B, int T, wm_stream_t stream);
+int wm_postproc_bwd(const float* g, const float* f_in, const float* stats, const float* taps, int ntaps, float thr,
+                    float max_rms, int stages, float* d_raw, int B, int T, wm_stream_t stream);
+
+/* ---- STFT loss stack: MultiScaleMelLoss :192-202, TFLoudnessLoss :204-217, high_freq_penalty :74-81 ---------
+ * loss_out: device scalar.  dsig (NULL = forward only): d loss / d (second signal | delta), [B,T].
+ * gframes: scratch [B, 1+T/hop, n_fft]; partial: scratch [B*(1+T/hop)].                                          */
+int wm_mel_loss(const float* clean, const float* wm, const float* fb, const int* klo, const int* khi, const int* mlo,
+                float* gframes, float* partial, float* loss_out, float* dsig, int B, int T, wm_stream_t stream);
+int wm_loud_loss(const float* clean, const float* wm, float thresh, float* gframes, float* partial, float* loss_out,
+                 float* dsig, int B, int T, wm_stream_t stream);
+int wm_hf_penalty(const float* delta, int kcut, float* gframes, float* partial, float* loss_out, float* dsig, int B, int T,
+                  wm_stream_t stream);
+
+/* ---- point-wise losses :252-266 and the optimizer update :504,:278 ------------------------------------------ */
+int wm_bce_fwd(const float* logits, const long long* message, float* partial, float* loc_out, float* bce_out, int B, int R,
+               int T, int NO, wm_stream_t stream);
+int wm_bce_bwd(const float* logits, const long long* message, const float* g_loc, const float* g_bce, float* dlogits, int B,
+               int R, int T, int NO, wm_stream_t stream);
+int wm_l1_fwd(const float* x, float* partial, float* out, long long n, wm_stream_t stream);
+int wm_l1_bwd(const float* x, const float* g, float* dx, long long n, wm_stream_t stream);
+int wm_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,
+                 int step, wm_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WM_HIP_H */

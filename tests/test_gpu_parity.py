@@ -1,0 +1,442 @@
+"""GPU parity tests: the HIP path (through the C ABI, via the drop-in modules) against the CPU oracle
+on the same seeded inputs, against the committed golden fixtures, and through size-independent
+properties at BASELINE.json's full sizes.
+
+Tolerances (north_star): fp32, 1e-4 relative for delta / logits / loss values.  'relative' is to the
+tensor's max magnitude (the reference's own CPU kernels differ from each other at that level too).
+Gradients: 2e-3 relative-to-max -- the fp32 reference itself is only reproducible to ~3e-4 there
+(tests/golden/oracle_vs_reference_report.txt was 3.4e-4 between two CPU formulations of BatchNorm).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import recipes as R
+from oracle import wm_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+FWD_TOL = 1e-4
+GRAD_TOL = 2e-3
+
+
+@pytest.fixture(scope="module")
+def awm():
+    import awm_amd
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    awm_amd.lib.load()
+    return awm_amd
+
+
+@pytest.fixture(scope="module")
+def dev():
+    return torch.device("cuda:0")
+
+
+def rel_err(a, ref):
+    a = a.detach().double().cpu()
+    ref = ref.detach().double().cpu()
+    return float((a - ref).abs().max() / (ref.abs().max() + 1e-30))
+
+
+def check(a, ref, tol, what=""):
+    assert a.shape == ref.shape, f"{what}: shape {tuple(a.shape)} vs {tuple(ref.shape)}"
+    e = rel_err(a, ref)
+    assert e <= tol, f"{what}: rel err {e:.3e} > {tol}"
+    return e
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale
+
+
+def states():
+    gsd, dsd = R.reference_layout_init()
+    R.perturb_bn_(gsd, R.BN_SEED_G)
+    R.perturb_bn_(dsd, R.BN_SEED_D)
+    return gsd, dsd
+
+
+def make_models(awm, dev, gsd=None, dsd=None):
+    if gsd is None:
+        gsd, dsd = states()
+    G, D = awm.Generator(16), awm.Detector(16)
+    G.load_state_dict(gsd)
+    D.load_state_dict(dsd)
+    return G.to(dev), D.to(dev), gsd, dsd
+
+
+# ------------------------------------------------------------------------------------------ thin layers
+@pytest.mark.parametrize("B,T", [(1, 16), (2, 1000), (3, 2052)])
+def test_stem(awm, dev, B, T):
+    from awm_amd import ops
+    s, w, b = rnd(B, 1, T, seed=1), rnd(64, 1, 7, seed=2, scale=0.3), rnd(64, seed=3, scale=0.1)
+    sr, wr, br = s.clone().requires_grad_(), w.clone().requires_grad_(), b.clone().requires_grad_()
+    yr = F.conv1d(sr, wr, br, padding=3)
+    g = rnd(B, 64, T, seed=4)
+    yr.backward(g)
+    sd, wd, bd = s.to(dev).requires_grad_(), w.to(dev).requires_grad_(), b.to(dev).requires_grad_()
+    y = ops.StemFn.apply(sd, wd, bd)
+    check(y, yr, FWD_TOL, "stem fwd")
+    y.backward(g.to(dev))
+    check(sd.grad, sr.grad, FWD_TOL, "stem ds")
+    check(wd.grad, wr.grad, FWD_TOL, "stem dw")
+    check(bd.grad, br.grad, FWD_TOL, "stem db")
+
+
+@pytest.mark.parametrize("B,T,NO", [(2, 1000, 17), (1, 260, 17), (2, 516, 1)])
+def test_heads(awm, dev, B, T, NO):
+    from awm_amd import ops
+    x, w, b = rnd(B, 64, T, seed=5), rnd(NO, 64, 1, seed=6, scale=0.2), rnd(NO, seed=7, scale=0.1)
+    xr, wr, br = x.clone().requires_grad_(), w.clone().requires_grad_(), b.clone().requires_grad_()
+    yr = F.conv1d(xr, wr, br).permute(0, 2, 1)
+    g = rnd(B, T, NO, seed=8)
+    yr.backward(g)
+    xd, wd, bd = x.to(dev).requires_grad_(), w.to(dev).requires_grad_(), b.to(dev).requires_grad_()
+    y = ops.HeadNFn.apply(xd, wd, bd)
+    check(y, yr, FWD_TOL, "headN fwd")
+    y.backward(g.to(dev))
+    check(xd.grad, xr.grad, FWD_TOL, "headN dx")
+    check(wd.grad, wr.grad, FWD_TOL, "headN dw")
+    check(bd.grad, br.grad, FWD_TOL, "headN db")
+    if NO == 1:
+        xd2, wd2, bd2 = x.to(dev).requires_grad_(), w.to(dev).requires_grad_(), b.to(dev).requires_grad_()
+        y1 = ops.Head1Fn.apply(xd2, wd2, bd2)
+        check(y1, yr.permute(0, 2, 1), FWD_TOL, "head1 fwd")
+        y1.backward(g.permute(0, 2, 1).contiguous().to(dev))
+        check(xd2.grad, xr.grad, FWD_TOL, "head1 dx")
+        check(wd2.grad, wr.grad, FWD_TOL, "head1 dw")
+        check(bd2.grad, br.grad, FWD_TOL, "head1 db")
+
+
+# ------------------------------------------------------------------------------------------ ResBlock
+def _resblock_state(seed):
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    for i, k in ((0, "block.0."), (3, "block.3.")):
+        sd[k + "weight"] = torch.randn(64, 64, 3, generator=g) * 0.08
+        sd[k + "bias"] = torch.randn(64, generator=g) * 0.05
+    for k in ("block.1.", "block.4."):
+        sd[k + "weight"] = 0.8 + 0.4 * torch.rand(64, generator=g)
+        sd[k + "bias"] = 0.05 * torch.randn(64, generator=g)
+        sd[k + "running_mean"] = 0.05 * torch.randn(64, generator=g)
+        sd[k + "running_var"] = 0.6 + 0.8 * torch.rand(64, generator=g)
+        sd[k + "num_batches_tracked"] = torch.tensor(3)
+    return sd
+
+
+@pytest.mark.parametrize("training", [False, True])
+@pytest.mark.parametrize("B,T", [(2, 1000), (1, 256), (3, 1284)])
+def test_resblock(awm, dev, training, B, T):
+    sd = _resblock_state(10 + B)
+    x = rnd(B, 64, T, seed=11).abs() * 0.7        # post-ReLU-like input
+    g = rnd(B, 64, T, seed=12)
+    sdr = {k: (v.clone().requires_grad_() if v.is_floating_point() and "running" not in k else v.clone()) for k, v in sd.items()}
+    xr = x.clone().requires_grad_()
+    new = {}
+    yr = O.resblock(sdr, "", xr, training, new)
+    yr.backward(g)
+    m = awm.ResBlock(64)
+    m.load_state_dict(sd)
+    m.to(dev).train(training)
+    xd = x.to(dev).requires_grad_()
+    y = m(xd)
+    check(y, yr, FWD_TOL, "resblock fwd")
+    y.backward(g.to(dev))
+    check(xd.grad, xr.grad, GRAD_TOL, "resblock dx")
+    for k, p in m.named_parameters():
+        if k.endswith("block.0.bias") or k.endswith("block.3.bias"):
+            if training:   # exactly-zero true gradient (bias in front of a batch-stat BN): only fp32 noise on both sides
+                assert float(p.grad.abs().max()) <= 1e-3 * float(sdr["block.0.weight"].grad.abs().max()) + 1e-4
+                continue
+        check(p.grad, sdr[k].grad, GRAD_TOL, f"resblock grad {k}")
+    if training:
+        st = m.state_dict()
+        for k, v in new.items():
+            if v.is_floating_point():
+                check(st[k], v, 1e-5, f"resblock new {k}")
+            else:
+                assert int(st[k]) == int(v)
+
+
+# ------------------------------------------------------------------------------------------ convT + embedding
+@pytest.mark.parametrize("with_msg", [True, False])
+def test_convT_embed(awm, dev, with_msg):
+    from awm_amd import ops
+    B, T = 2, 1000
+    x, w, b = rnd(B, 64, T, seed=20), rnd(64, 64, 7, seed=21, scale=0.05), rnd(64, seed=22, scale=0.1)
+    table = rnd(50, 64, seed=23)
+    msg = torch.tensor([7, 7]) if with_msg else None      # duplicate rows exercise the scatter-add
+    xr, wr, br, tr = (t.clone().requires_grad_() for t in (x, w, b, table))
+    xin = xr + tr[msg].unsqueeze(-1) if with_msg else xr
+    yr = F.conv_transpose1d(xin, wr, br, padding=3)
+    g = rnd(B, 64, T, seed=24)
+    yr.backward(g)
+    xd, wd, bd, td = (t.to(dev).requires_grad_() for t in (x, w, b, table))
+    vec = ops.EmbedFn.apply(td, msg.to(dev)) if with_msg else None
+    y = ops.ConvT7Fn.apply(xd, vec, wd, bd)
+    check(y, yr, FWD_TOL, "convT fwd")
+    y.backward(g.to(dev))
+    check(xd.grad, xr.grad, FWD_TOL, "convT dx")
+    check(wd.grad, wr.grad, FWD_TOL, "convT dw")
+    check(bd.grad, br.grad, FWD_TOL, "convT db")
+    if with_msg:
+        check(td.grad, tr.grad, FWD_TOL, "embedding grad")
+
+
+# ------------------------------------------------------------------------------------------ LSTM
+@pytest.mark.parametrize("B,T", [(2, 48), (1, 100), (3, 1000)])
+def test_lstm_small(awm, dev, B, T):
+    from awm_amd import ops
+    g = torch.Generator().manual_seed(30)
+    k = 1.0 / 8.0
+    wi, wh = (torch.rand(256, 64, generator=g) * 2 - 1) * k, (torch.rand(256, 64, generator=g) * 2 - 1) * k
+    bi, bh = (torch.rand(256, generator=g) * 2 - 1) * k, (torch.rand(256, generator=g) * 2 - 1) * k
+    x = rnd(B, 64, T, seed=31)
+    xr, wir, whr, bir, bhr = (t.clone().requires_grad_() for t in (x, wi, wh, bi, bh))
+    hr = O.lstm_forward(xr.permute(0, 2, 1), wir, whr, bir, bhr).permute(0, 2, 1)
+    gg = rnd(B, 64, T, seed=32)
+    hr.backward(gg)
+    xd, wid, whd, bid, bhd = (t.to(dev).requires_grad_() for t in (x, wi, wh, bi, bh))
+    h = ops.LSTMFn.apply(xd, wid, whd, bid, bhd)
+    check(h, hr, FWD_TOL, "lstm fwd")
+    h.backward(gg.to(dev))
+    check(xd.grad, xr.grad, GRAD_TOL, "lstm dx")
+    check(wid.grad, wir.grad, GRAD_TOL, "lstm dW_ih")
+    check(whd.grad, whr.grad, GRAD_TOL, "lstm dW_hh")
+    check(bid.grad, bir.grad, GRAD_TOL, "lstm db_ih")
+    check(bhd.grad, bhr.grad, GRAD_TOL, "lstm db_hh")
+
+
+def test_lstm_long_horizon(awm, dev):
+    """all 16000 dependent steps (SURVEY.md hard part 1): drift must stay inside 1e-4"""
+    from awm_amd import ops
+    gsd, _ = states()
+    x = rnd(2, 64, 16000, seed=33).abs() * 0.5
+    wi, wh, bi, bh = (gsd["lstm." + k] for k in ("weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0"))
+    h0 = torch.zeros(1, 2, 64)
+    with torch.no_grad():
+        ref, _, _ = torch.lstm(x.permute(0, 2, 1), (h0, h0.clone()), (wi, wh, bi, bh), True, 1, 0.0, False, False, True)
+        h = ops.LSTMFn.apply(x.to(dev), wi.to(dev), wh.to(dev), bi.to(dev), bh.to(dev))
+    check(h, ref.permute(0, 2, 1), FWD_TOL, "lstm 16000 steps")
+    check(h[:, :, -64:], ref.permute(0, 2, 1)[:, :, -64:], FWD_TOL, "lstm tail")
+
+
+# ------------------------------------------------------------------------------------------ post-processing
+@pytest.mark.parametrize("scale", [0.03, 0.001])
+def test_postprocess(awm, dev, scale):
+    d = rnd(3, 1, 16000, seed=40, scale=scale)
+    dr = d.clone().requires_grad_()
+    yr = O.postprocess(dr)
+    g = rnd(3, 1, 16000, seed=41)
+    yr.backward(g)
+    dd = d.to(dev).requires_grad_()
+    y = awm.postprocess(dd)
+    check(y, yr, 1e-5, "postprocess fwd")
+    y.backward(g.to(dev))
+    check(dd.grad, dr.grad, 1e-4, "postprocess bwd")
+    # the three reference functions one by one
+    with torch.no_grad():
+        check(awm.fir_lowpass(d.to(dev)), O.fir_lowpass(d), 1e-5, "fir")
+        check(awm.clamp_peak(d.to(dev)), O.clamp_peak(d), 1e-6, "clamp")
+        check(awm.limit_rms(d.to(dev)), O.limit_rms(d), 1e-5, "rms")
+        assert float(y.abs().max()) <= 0.02 + 1e-7
+        assert float(torch.sqrt((y ** 2).mean(dim=[1, 2])).max()) <= 0.005 * (1 + 1e-5)
+
+
+# ------------------------------------------------------------------------------------------ loss stack
+@pytest.mark.parametrize("B,T", [(2, 16000), (1, 4000)])
+def test_spectral_losses(awm, dev, B, T):
+    s = O.synthetic_clips(B, seed=50, T=T)
+    d = rnd(B, 1, T, seed=51, scale=0.004)
+    for name, ofn, hfn in (("mel", lambda w: O.mel_loss(s, w), lambda w: awm.MultiScaleMelLoss()(s.to(dev), w)),
+                           ("loud", lambda w: O.loudness_loss(s, w), lambda w: awm.TFLoudnessLoss()(s.to(dev), w))):
+        wr = (s + d).requires_grad_()
+        lr = ofn(wr)
+        lr.backward()
+        wd = (s + d).to(dev).requires_grad_()
+        lh = hfn(wd)
+        check(lh.reshape(1), lr.reshape(1), FWD_TOL, f"{name} value")
+        (3.0 * lh).backward()
+        check(wd.grad, 3.0 * wr.grad, GRAD_TOL, f"{name} grad")
+    dr = d.clone().requires_grad_()
+    lr = O.high_freq_penalty(dr)
+    lr.backward()
+    dd = d.to(dev).requires_grad_()
+    lh = awm.high_freq_penalty(dd)
+    check(lh.reshape(1), lr.reshape(1), FWD_TOL, "hf value")
+    lh.backward()
+    check(dd.grad, dr.grad, GRAD_TOL, "hf grad")
+
+
+def test_pointwise_losses(awm, dev):
+    B, T = 3, 1000
+    logits = rnd(2 * B, T, 17, seed=60, scale=3.0)
+    msg = torch.tensor([0, 65535, 0b1010011100101101])
+    lr_ = logits.clone().requires_grad_()
+    tgt = torch.cat([torch.ones(B, T), torch.zeros(B, T)])
+    loc_r = F.binary_cross_entropy_with_logits(lr_[:, :, 0], tgt)
+    bits = O.message_bits_target(msg).unsqueeze(1).expand(-1, T, -1)
+    bce_r = F.binary_cross_entropy_with_logits(lr_[:B, :, 1:], bits)
+    (10.0 * loc_r + 1.0 * bce_r).backward()
+    ld = logits.to(dev).requires_grad_()
+    loc, bce = awm.detection_losses(ld, msg.to(dev))
+    check(loc.reshape(1), loc_r.reshape(1), 1e-5, "loc")
+    check(bce.reshape(1), bce_r.reshape(1), 1e-5, "bce")
+    (10.0 * loc + 1.0 * bce).backward()
+    check(ld.grad, lr_.grad, 1e-4, "bce grads")
+    d = rnd(2, 1, 16000, seed=61, scale=0.01)
+    dr = d.clone().requires_grad_()
+    dr.abs().mean().backward()
+    dd = d.to(dev).requires_grad_()
+    l1 = awm.l1_to_zero(dd)
+    check(l1.reshape(1), d.abs().mean().reshape(1), 1e-5, "l1")
+    l1.backward()
+    check(dd.grad, dr.grad, 1e-5, "l1 grad")
+
+
+# ------------------------------------------------------------------------------------------ whole networks vs golden fixtures
+def test_g1_eval_forward_golden(awm, dev, golden):
+    G, D, gsd, dsd = make_models(awm, dev)
+    G.eval(); D.eval()
+    s = O.synthetic_clips(2, seed=1234)
+    msg = torch.from_numpy(golden["g1_message"])
+    with torch.no_grad():
+        d = G(s.to(dev), msg.to(dev))
+        check(d, torch.from_numpy(golden["g1_delta"]), FWD_TOL, "G1 delta vs reference fixture")
+        d0 = G(s.to(dev))
+        check(d0[..., ::97], torch.from_numpy(golden["g1_delta_nomsg_sub"]), FWD_TOL, "G1 delta (message omitted)")
+        dp = awm.postprocess(d)
+        check(dp, torch.from_numpy(golden["g1_delta_post"]), FWD_TOL, "G1 delta_post")
+        lg = D(torch.cat([s.to(dev) + dp, s.to(dev)], 0))
+        assert lg.shape == (4, 16000, 17)
+        check(lg[:, ::97, :], torch.from_numpy(golden["g1_logits_sub"]), FWD_TOL, "G1 logits")
+        chk = golden["g1_logits_chk"]
+        assert abs(float(lg.double().sum()) - chk[0]) <= 1e-4 * chk[1]
+
+
+def test_g3_shipped_detector_checkpoint(awm, dev, golden):
+    ck = np.load(os.path.join(os.path.dirname(__file__), "golden", "detector_best_unprefixed.npz"))
+    sd = {"_orig_mod." + k: torch.from_numpy(ck[k]) for k in ck.files}      # as shipped: torch.compile prefix
+    D = awm.Detector(16)
+    res = awm.load_state_dict_strip_prefix(D, sd)
+    assert not res.missing_keys and not res.unexpected_keys
+    D.to(dev).eval()
+    s = O.synthetic_clips(2, seed=1234)
+    with torch.no_grad():
+        lg = D(s.to(dev))
+    check(lg[:, ::97, :], torch.from_numpy(golden["g3_logits_sub"]), FWD_TOL, "G3 logits")
+    check(torch.sigmoid(lg[:, :, 0]).mean(dim=1), torch.from_numpy(golden["g3_mean_prob"]), FWD_TOL, "G3 mean prob")
+
+
+def test_g2_train_step_golden(awm, dev, golden):
+    G, D, gsd, dsd = make_models(awm, dev)
+    G.train(); D.train()
+    s = O.synthetic_clips(4, seed=1235)
+    msg = torch.from_numpy(golden["g2_message"])
+    total, out = awm.forward_losses(G, D, s.to(dev), msg.to(dev))
+    total.backward()
+    for k in ("l1", "mel", "loud", "loc", "bce", "hf", "total"):
+        check(out[k].reshape(1), torch.tensor([float(golden[f"g2_{k}"])]), FWD_TOL, f"G2 {k}")
+    check(out["delta_raw"][..., ::97], torch.from_numpy(golden["g2_delta_raw_sub"]), FWD_TOL, "G2 delta_raw")
+    check(out["delta"][..., ::97], torch.from_numpy(golden["g2_delta_sub"]), FWD_TOL, "G2 delta")
+    check(out["logits"][:, ::97, :], torch.from_numpy(golden["g2_logits_sub"]), FWD_TOL, "G2 logits")
+    gp, dp = dict(G.named_parameters()), dict(D.named_parameters())
+    check(gp["encoder.0.weight"].grad, torch.from_numpy(golden["g2_grad_g_encoder0_weight"]), GRAD_TOL, "grad enc0")
+    check(gp["lstm.weight_hh_l0"].grad, torch.from_numpy(golden["g2_grad_g_lstm_whh"]), GRAD_TOL, "grad W_hh")
+    check(gp["lstm.weight_ih_l0"].grad, torch.from_numpy(golden["g2_grad_g_lstm_wih"]), GRAD_TOL, "grad W_ih")
+    check(gp["embedding.weight"].grad[msg.to(dev)], torch.from_numpy(golden["g2_grad_g_emb_rows"]), GRAD_TOL, "grad emb rows")
+    check(gp["decoder.0.weight"].grad[::4, ::4], torch.from_numpy(golden["g2_grad_g_dec0_weight_sub"]), GRAD_TOL, "grad dec0")
+    check(gp["encoder.1.block.0.weight"].grad[::4, ::4], torch.from_numpy(golden["g2_grad_g_enc1_b0_weight_sub"]), GRAD_TOL, "grad enc1 conv")
+    check(gp["encoder.1.block.1.weight"].grad, torch.from_numpy(golden["g2_grad_g_enc1_bn1_weight"]), GRAD_TOL, "grad enc1 bn")
+    check(dp["model.3.weight"].grad, torch.from_numpy(golden["g2_grad_d_model3_weight"]), GRAD_TOL, "grad D head")
+    check(dp["model.0.weight"].grad, torch.from_numpy(golden["g2_grad_d_model0_weight"]), GRAD_TOL, "grad D stem")
+    check(dp["model.1.block.4.bias"].grad, torch.from_numpy(golden["g2_grad_d_m1_bn4_bias"]), GRAD_TOL, "grad D bn bias")
+    gst, dst = G.state_dict(), D.state_dict()
+    check(gst["encoder.1.block.1.running_mean"], torch.from_numpy(golden["g2_new_g_enc1_bn1_rm"]), 1e-5, "running mean")
+    check(gst["encoder.1.block.1.running_var"], torch.from_numpy(golden["g2_new_g_enc1_bn1_rv"]), 1e-5, "running var")
+    check(dst["model.2.block.4.running_mean"], torch.from_numpy(golden["g2_new_d_m2_bn4_rm"]), 1e-5, "D running mean")
+    check(dst["model.2.block.4.running_var"], torch.from_numpy(golden["g2_new_d_m2_bn4_rv"]), 1e-5, "D running var")
+    assert int(gst["encoder.1.block.1.num_batches_tracked"]) == 4
+    # embedding gradient is dense and zero off the looked-up rows (reference: nn.Embedding sparse=False)
+    eg = gp["embedding.weight"].grad
+    assert eg.shape == (65536, 64)
+    mask = torch.ones(65536, dtype=torch.bool, device=dev); mask[msg.to(dev)] = False
+    assert float(eg[mask].abs().max()) == 0.0
+
+
+def test_all_grads_vs_oracle(awm, dev):
+    """every parameter gradient of a train step against the oracle's CPU autograd (short clips)"""
+    G, D, gsd, dsd = make_models(awm, dev)
+    G.train(); D.train()
+    B, T = 3, 4000
+    s = O.synthetic_clips(B, seed=70, T=T)
+    msg = O.synthetic_messages(B, seed=71)
+    g2 = {k: v.clone().requires_grad_(v.dtype.is_floating_point and "running" not in k) for k, v in gsd.items()}
+    d2 = {k: v.clone().requires_grad_(v.dtype.is_floating_point and "running" not in k) for k, v in dsd.items()}
+    tot_r, out_r = O.step_losses(g2, d2, s, msg, training=True, g_stats={}, d_stats={})
+    tot_r.backward()
+    total, out = awm.forward_losses(G, D, s.to(dev), msg.to(dev))
+    total.backward()
+    for k in ("l1", "mel", "loud", "loc", "bce", "hf", "raw_total", "total"):
+        check(out[k].reshape(1), out_r[k].reshape(1), FWD_TOL, f"step {k}")
+    worst = 0.0
+    wscale = {}
+    for name, mod, ref in (("G", G, g2), ("D", D, d2)):
+        for k, p in mod.named_parameters():
+            rg = ref[k].grad
+            if k.endswith("block.0.bias") or k.endswith("block.3.bias"):
+                continue          # exactly-zero true gradient, fp32 noise on both sides
+            e = rel_err(p.grad, rg)
+            worst = max(worst, e)
+            assert e <= GRAD_TOL, f"{name}.{k}: grad rel err {e:.3e}"
+    print("worst grad rel err", worst)
+
+
+# ------------------------------------------------------------------------------------------ full-size properties
+def test_batch_invariance_full_size(awm, dev):
+    """BASELINE config 2 size (B=64, eval): clips are independent units, so a clip's delta / logits must
+    not depend on which batch it rides in (bit-exact: no cross-clip arithmetic in eval mode)."""
+    G, D, _, _ = make_models(awm, dev)
+    G.eval(); D.eval()
+    s = O.synthetic_clips(64, seed=80).to(dev)
+    msg = O.synthetic_messages(64, seed=81).to(dev)
+    with torch.no_grad():
+        d = G(s, msg)
+        lg = D(torch.cat([s + awm.postprocess(d), s], 0))
+        for i in (0, 37, 63):
+            di = G(s[i:i + 1], msg[i:i + 1])
+            assert torch.equal(di, d[i:i + 1]), f"clip {i}: delta depends on the batch"
+            li = D((s[i:i + 1] + awm.postprocess(di)))
+            assert torch.equal(li, lg[i:i + 1]), f"clip {i}: logits depend on the batch"
+    assert torch.isfinite(d).all() and torch.isfinite(lg).all()
+    assert lg.shape == (128, 16000, 17)
+
+
+def test_message_linearity_of_embedding_path(awm, dev):
+    """delta(message) - delta(no message) flows only through the (linear) convT + embedding add in front of
+    decoder.1; with the ResBlock after it that is not linear, but an all-zero embedding row must reproduce
+    the message-free output exactly."""
+    G, _, _, _ = make_models(awm, dev)
+    G.eval()
+    with torch.no_grad():
+        G.embedding.weight[123].zero_()
+        s = O.synthetic_clips(2, seed=90, T=4000).to(dev)
+        a = G(s, torch.tensor([123, 123], device=dev))
+        b = G(s)
+    assert torch.equal(a, b)
+
+
+def test_errors(awm, dev):
+    G = awm.Generator(16).to(dev)
+    with pytest.raises(ValueError):
+        G(torch.zeros(2, 1, 16001, device=dev))
+    with pytest.raises(ValueError):
+        G(torch.zeros(2, 1, 16000, device=dev), torch.zeros(3, dtype=torch.int64, device=dev))
+    with pytest.raises(RuntimeError):
+        G(torch.zeros(2, 1, 16000))
+    with pytest.raises(ValueError):
+        awm.ResBlock(64).to(dev)(torch.zeros(1, 32, 64, device=dev))
