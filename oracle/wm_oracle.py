@@ -180,7 +180,7 @@ def fir_kernel(cutoff: float = 4000.0, taps: int = 101) -> Tensor:
 
 
 def fir_lowpass(delta: Tensor, cutoff: float = 4000.0, taps: int = 101) -> Tensor:
-    k = fir_kernel(cutoff, taps).to(delta.device).view(1, 1, -1)
+    k = fir_kernel(cutoff, taps).to(delta.device, delta.dtype).view(1, 1, -1)
     return F.conv1d(delta, k, padding=(taps - 1) // 2)                             # :64
 
 
@@ -205,7 +205,7 @@ def postprocess(delta: Tensor) -> Tensor:
 def _stft(x: Tensor, n_fft: int, hop: int) -> Tensor:
     """torch.stft defaults used by the reference: periodic hann, center=True,
     reflect pad, onesided, not normalised.  x (B,T) -> complex (B, n_fft/2+1, frames)."""
-    win = torch.hann_window(n_fft, device=x.device)
+    win = torch.hann_window(n_fft, device=x.device).to(x.dtype)
     return torch.stft(x, n_fft, hop, window=win, return_complex=True)
 
 
@@ -213,7 +213,7 @@ def high_freq_penalty(delta: Tensor, cutoff: float = 3500.0, n_fft: int = 512) -
     """py/main16.py:74-81; masked-out bins still count in the mean's denominator."""
     spec = _stft(delta.squeeze(1), n_fft, n_fft // 4).abs()
     freqs = torch.fft.rfftfreq(n_fft, 1 / SAMPLE_RATE).to(delta.device)
-    mask = (freqs > cutoff).float().view(1, -1, 1)
+    mask = (freqs > cutoff).to(spec.dtype).view(1, -1, 1)
     return (spec * mask).mean()
 
 
@@ -238,7 +238,7 @@ def mel_spectrogram(x: Tensor, n_fft: int = 1024, hop: int = 256, n_mels: int = 
     """MelSpectrogram(sample_rate=16000, n_fft=1024, hop_length=256, n_mels=64), power 2.
     x (B,1,T) -> (B,1,n_mels,frames)."""
     p = _stft(x.reshape(-1, x.shape[-1]), n_fft, hop).abs().pow(2.0)       # (B,F,frames)
-    fb = mel_filterbank(n_fft // 2 + 1, n_mels).to(x.device)
+    fb = mel_filterbank(n_fft // 2 + 1, n_mels).to(x.device, x.dtype)
     mel = torch.matmul(p.transpose(-1, -2), fb).transpose(-1, -2)
     return mel.reshape(x.shape[:-1] + mel.shape[-2:])
 
@@ -252,7 +252,7 @@ def loudness_loss(clean: Tensor, wm: Tensor) -> Tensor:
     """TFLoudnessLoss.forward, py/main16.py:210-217 (n_fft 2048, hop 512, mask from |S_clean|>0.01)."""
     sc = _stft(clean.squeeze(1), 2048, 512)
     sw = _stft(wm.squeeze(1), 2048, 512)
-    mask = (sc.abs() > 0.01).float()
+    mask = (sc.abs() > 0.01).to(sc.real.dtype)
     return (((sw.abs() - sc.abs()) ** 2) * mask).mean()
 
 
@@ -277,9 +277,9 @@ def step_losses(gsd: State, dsd: State, s: Tensor, message: Tensor, *, training:
     s_w = s + delta
     logits = detector_forward(dsd, torch.cat([s_w, s], dim=0), training=training, new_stats=d_stats)
     det, dec = logits[:, :, 0], logits[:B, :, 1:]
-    tgt = torch.cat([torch.ones(B, T), torch.zeros(B, T)], dim=0).to(s.device)
+    tgt = torch.cat([torch.ones(B, T), torch.zeros(B, T)], dim=0).to(s.device, s.dtype)
     loc = F.binary_cross_entropy_with_logits(det, tgt)
-    bits = message_bits_target(message, dec.shape[-1]).unsqueeze(1).expand(-1, T, -1)
+    bits = message_bits_target(message, dec.shape[-1]).to(s.dtype).unsqueeze(1).expand(-1, T, -1)
     bce = F.binary_cross_entropy_with_logits(dec, bits)
     l1 = delta.abs().mean()
     mel = mel_loss(s, s_w)

@@ -138,8 +138,21 @@ def main():
 
     # ------------------------------------------------------------------ G2: train-mode step, B=4
     B = 4
-    s4 = O.synthetic_clips(B, seed=1235)
-    msg4 = O.synthetic_messages(B, seed=4322)
+    # clamp_peak's derivative is discontinuous at |f| = 0.02: a sample sitting within fp32 round-off of the
+    # threshold flips between "gradient passes" and "gradient blocked" across implementations (seen: ONE such
+    # sample moved every Generator gradient by ~1e-2).  Pick the first clip seed whose FIR output keeps a
+    # margin of >= 1e-5 * max|f| (about 5x the fp32 noise of f) from the threshold, and record it in the fixture.
+    for g2_seed in range(1235, 1400):
+        s4 = O.synthetic_clips(B, seed=g2_seed)
+        msg4 = O.synthetic_messages(B, seed=4322)
+        with torch.no_grad():
+            f_probe = O.fir_lowpass(O.generator_forward(gsd, s4, msg4, training=True))
+        margin = float((f_probe.abs() - 0.02).abs().min())
+        if margin >= 1e-5 * float(f_probe.abs().max()):
+            break
+    print(f"G2 clip seed {g2_seed}: clamp margin {margin:.2e}, clamped fraction {float((f_probe.abs() > 0.02).float().mean()):.3f}")
+    fx["g2_seed"] = np.array(g2_seed)
+    fx["g2_clamp_margin"] = np.array(margin)
     refG.train(); refD.train()
     refG.zero_grad(); refD.zero_grad()
     loud_mod = ref["TFLoudnessLoss"]()

@@ -335,7 +335,9 @@ def test_g3_shipped_detector_checkpoint(awm, dev, golden):
 def test_g2_train_step_golden(awm, dev, golden):
     G, D, gsd, dsd = make_models(awm, dev)
     G.train(); D.train()
-    s = O.synthetic_clips(4, seed=1235)
+    # the fixture generator picked a clip seed with no sample within fp32 round-off of the clamp threshold
+    # (clamp_peak's derivative is discontinuous there; see tests/golden/make_golden.py)
+    s = O.synthetic_clips(4, seed=int(golden["g2_seed"]))
     msg = torch.from_numpy(golden["g2_message"])
     total, out = awm.forward_losses(G, D, s.to(dev), msg.to(dev))
     total.backward()
@@ -373,8 +375,13 @@ def test_all_grads_vs_oracle(awm, dev):
     G, D, gsd, dsd = make_models(awm, dev)
     G.train(); D.train()
     B, T = 3, 4000
-    s = O.synthetic_clips(B, seed=70, T=T)
     msg = O.synthetic_messages(B, seed=71)
+    for seed in range(70, 170):      # keep every sample away from clamp_peak's derivative discontinuity
+        s = O.synthetic_clips(B, seed=seed, T=T)
+        with torch.no_grad():
+            f = O.fir_lowpass(O.generator_forward(gsd, s, msg, training=True))
+        if float((f.abs() - 0.02).abs().min()) >= 1e-5 * float(f.abs().max()):
+            break
     g2 = {k: v.clone().requires_grad_(v.dtype.is_floating_point and "running" not in k) for k, v in gsd.items()}
     d2 = {k: v.clone().requires_grad_(v.dtype.is_floating_point and "running" not in k) for k, v in dsd.items()}
     tot_r, out_r = O.step_losses(g2, d2, s, msg, training=True, g_stats={}, d_stats={})

@@ -88,7 +88,7 @@ def test_g2_train_step(golden, states):
     gsd, dsd = states
     g2 = {k: v.clone().requires_grad_(v.dtype.is_floating_point and "running" not in k) for k, v in gsd.items()}
     d2 = {k: v.clone().requires_grad_(v.dtype.is_floating_point and "running" not in k) for k, v in dsd.items()}
-    s = O.synthetic_clips(4, seed=1235)
+    s = O.synthetic_clips(4, seed=int(golden["g2_seed"]))
     msg = torch.from_numpy(golden["g2_message"])
     gst, dst = {}, {}
     total, out = O.step_losses(g2, d2, s, msg, training=True, g_stats=gst, d_stats=dst)
