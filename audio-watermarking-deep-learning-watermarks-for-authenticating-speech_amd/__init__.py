@@ -4,8 +4,10 @@ from .modules import Detector, Generator, ResBlock, load_state_dict_strip_prefix
 from .losses import (MultiScaleMelLoss, TFLoudnessLoss, clamp_peak, detection_losses, fir_lowpass, high_freq_penalty,
                      l1_to_zero, limit_rms, postprocess)
 from .step import LOSS_WEIGHTS, forward_losses, train_step, eval_forward
+from .optim import FlatAdam
+from . import distributed
 from ._lib import lib, LIB_PATH
 
 __all__ = ["Generator", "Detector", "ResBlock", "load_state_dict_strip_prefix", "MultiScaleMelLoss", "TFLoudnessLoss",
            "fir_lowpass", "clamp_peak", "limit_rms", "postprocess", "high_freq_penalty", "detection_losses", "l1_to_zero",
-           "forward_losses", "train_step", "eval_forward", "LOSS_WEIGHTS", "lib", "LIB_PATH"]
+           "forward_losses", "train_step", "eval_forward", "LOSS_WEIGHTS", "FlatAdam", "distributed", "lib", "LIB_PATH"]

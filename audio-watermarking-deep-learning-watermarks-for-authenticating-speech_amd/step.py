@@ -34,11 +34,14 @@ def forward_losses(generator, detector, s, message):
                               bce=bce, hf=hf, raw_total=raw, total=total)
 
 
-def train_step(generator, detector, optimizer, s, message):
-    """One iteration of train_one_epoch's loop body (:242-278): zero_grad, forward, backward, optimizer step."""
-    optimizer.zero_grad(set_to_none=True)
+def train_step(generator, detector, optimizer, s, message, grad_sync=None):
+    """One iteration of train_one_epoch's loop body (:242-278): zero_grad, forward, backward, optimizer step.
+    `grad_sync` (optional callable) runs between backward and the update -- the data-parallel all-reduce."""
+    optimizer.zero_grad(set_to_none=not hasattr(optimizer, "flat"))
     total, out = forward_losses(generator, detector, s, message)
     total.backward()
+    if grad_sync is not None:
+        grad_sync()
     optimizer.step()
     return out
 

@@ -1,0 +1,206 @@
+#!/usr/bin/env python
+"""bench.py -- clips/s of the watermark embed+detect train step (BASELINE.json metric) on N MI355X.
+
+A "step" is one pass of the reference's hot loop body (py/main16.py:242-278) over one synthetic batch:
+Generator -> fir/clamp/rms -> Detector on [watermarked; clean] -> {l1, mel, loud, loc, bce, hf} -> backward
+-> Adam update, fp32, inputs resident in HBM.  N=1 workload = BASELINE.json configs[2] (B=256 train step);
+N>1 = configs[3]: the same per-GPU batch on every rank (weak scaling) + one RCCL all-reduce of the flat
+gradient bucket.  Prints ONE JSON line on rank 0.
+
+  python bench.py --gpus 1 --steps 5 --warmup 2
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+T = 16000
+PEAK_FP32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_HBM_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E spec (6.3 TB/s achievable)
+
+
+def synthetic_batch(batch, rank, dev):
+    """s = clamp(0.1*randn, +-0.99), seed 1234+rank; message uniform in [0, 65536), seed 4321+rank"""
+    g = torch.Generator().manual_seed(1234 + rank)
+    s = (0.1 * torch.randn(batch, 1, T, generator=g)).clamp_(-0.99, 0.99)
+    g2 = torch.Generator().manual_seed(4321 + rank)
+    msg = torch.randint(0, 65536, (batch,), generator=g2, dtype=torch.int64)
+    return s.to(dev), msg.to(dev)
+
+
+class LaunchTimer:
+    """HIP-event bracket around every launch of one C-ABI entry point that matches `pred`, recorded on the
+    stream the kernel is launched on (torch's current stream == the stream handed to the launcher)."""
+
+    def __init__(self, lib, name, pred):
+        self.events, self.on = [], False
+        orig = getattr(lib, name)
+
+        def wrapped(*a):
+            if self.on and pred(a):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                orig(*a)
+                e1.record()
+                self.events.append((e0, e1, a[12]))          # a[12] = clips in this launch
+            else:
+                orig(*a)
+        setattr(lib, name, wrapped)
+
+    def mean_ms(self):
+        if not self.events:
+            return None
+        return sum(a.elapsed_time(b) for a, b, _ in self.events) / len(self.events)
+
+    def mean_clips(self):
+        return sum(c for _, _, c in self.events) / len(self.events)
+
+
+def cpu_baseline(sample_batch=8, steps=2):
+    """The oracle (CPU restatement, kind "port") timed on this box's host cores on a bounded sample of the same
+    workload: B=8 train steps (fwd + bwd + Adam), 1 warm-up + `steps` timed."""
+    from oracle import recipes as R
+    from oracle import wm_oracle as O
+    nthreads = torch.get_num_threads()
+    gsd, dsd = R.reference_layout_init()
+    params = []
+    for sd in (gsd, dsd):
+        for k, v in sd.items():
+            if v.is_floating_point() and "running" not in k:
+                v.requires_grad_(True)
+                params.append(v)
+    opt = torch.optim.Adam(params, lr=1e-3)
+    s = O.synthetic_clips(sample_batch, seed=1234)
+    msg = O.synthetic_messages(sample_batch, seed=4321)
+
+    def one():
+        opt.zero_grad()
+        total, _ = O.step_losses(gsd, dsd, s, msg, training=True, g_stats={}, d_stats={})
+        total.backward()
+        opt.step()
+    one()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one()
+    dt = (time.perf_counter() - t0) / steps
+    return {"value": sample_batch / dt, "unit": "clips/s", "cores": nthreads, "kind": "port",
+            "sample": f"oracle/wm_oracle.py train step (fwd+bwd+Adam), B={sample_batch}, 1 warm-up + {steps} timed steps, "
+                      f"{dt:.2f} s/step, torch CPU fp32 with {nthreads} threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=256, help="clips per GPU (BASELINE configs[2]/[3]: 256)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--torch-adam", action="store_true", help="use torch.optim.Adam instead of the fused flat Adam")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import awm_amd
+    from awm_amd import distributed as wmd
+    awm_amd.lib.load()                                  # fail loudly if the HIP library is missing
+
+    torch.manual_seed(42)                               # weights: PyTorch default init under manual_seed(42)
+    G, D = awm_amd.Generator(16), awm_amd.Detector(16)
+    G.to(dev).train(); D.to(dev).train()
+    wmd.broadcast_parameters([G, D])
+    if args.torch_adam:
+        opt = torch.optim.Adam(list(G.parameters()) + list(D.parameters()), lr=1e-3)
+        sync = (lambda: wmd.allreduce_gradients(list(G.parameters()) + list(D.parameters()))) if world > 1 else None
+    else:
+        opt = awm_amd.FlatAdam([G, D], lr=1e-3)
+        sync = (lambda: wmd.allreduce_flat_gradient(opt.grad)) if world > 1 else None
+    s, msg = synthetic_batch(args.batch, rank, dev)
+
+    # dominant kernel: the 64->64 k3 forward convolution of the ResBlocks (wm_conv64, KW=3, epi=bias)
+    timer = LaunchTimer(awm_amd.lib, "wm_conv64", lambda a: a[14] == 3 and a[16] == 0)
+
+    def step():
+        return awm_amd.train_step(G, D, opt, s, msg, grad_sync=sync)
+
+    for _ in range(args.warmup):
+        step()
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    timer.on = True
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    fence()
+    dt = time.perf_counter() - t0
+    timer.on = False
+    if world > 1:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    total_loss = float(out["total"])
+    assert total_loss == total_loss, "NaN loss"
+
+    if rank == 0:
+        ms_step = 1e3 * dt / args.steps
+        value = args.batch * world * args.steps / dt
+        k_ms = timer.mean_ms()
+        # Generator-side launches carry B clips, Detector-side ones 2B ([watermarked; clean]): use what was launched
+        clips_per_launch = timer.mean_clips() if k_ms else 0.0
+        flops_launch = 2.0 * 64 * 64 * 3 * T * clips_per_launch
+        bytes_launch = 2.0 * 64 * T * 4 * clips_per_launch
+        roofline = None
+        if k_ms:
+            ach = flops_launch / (k_ms * 1e-3) / 1e12
+            roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                        "kernel": "conv64_kernel<KW=3> forward (wm_conv64: Conv1d(64,64,3)+bias, BN+ReLU fused on load, BN sums in epilogue)",
+                        "avg_launch_ms": round(k_ms, 4), "launches_timed": len(timer.events),
+                        "algorithmic_flops_per_launch": flops_launch, "algorithmic_bytes_per_launch": bytes_launch,
+                        "hbm_achieved_GBs": round(bytes_launch / (k_ms * 1e-3) / 1e9, 1),
+                        "hbm_frac_of_8TBs": round(bytes_launch / (k_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
+        line = {"metric": "1-s@16kHz clips/sec (gen+det+loss fwd-bwd)", "value": round(value, 2), "unit": "clips/s",
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 3),
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": f"main16 train step: Generator+Detector+6 losses fwd-bwd + Adam, B={args.batch} clips/GPU "
+                                       f"x {world} GPU, 1-s @ 16 kHz, message_bits=16 (BASELINE configs[{2 if world == 1 else 3}])",
+                           "batch_per_gpu": args.batch, "global_batch": args.batch * world, "clip_len": T,
+                           "optimizer": "torch.optim.Adam" if args.torch_adam else "fused flat Adam (wm_adam_step)",
+                           "parallelism": f"dp{world}" if world > 1 else "single"},
+                "loss": round(total_loss, 6), "roofline": roofline}
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
