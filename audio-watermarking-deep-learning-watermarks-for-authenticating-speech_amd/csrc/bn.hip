@@ -10,18 +10,36 @@ using namespace wm;
 
 namespace {
 
-// partials: [nparts][2][64] (sum, sum of squares) ; one 64-thread block
-__global__ void bn_finalize_kernel(const float* __restrict__ partials, int nparts, double count,
+// sum partials[p][which][c] over p in double: 1024 threads = 64 channels x 16 slices, LDS tree at the end
+__device__ __forceinline__ void reduce_partials_1024(const float* __restrict__ partials, int nparts, double& s1, double& s2,
+                                                     double (*red)[2][64]) {
+    const int c = threadIdx.x & 63, j = threadIdx.x >> 6;
+    double a = 0.0, b = 0.0;
+    for (int p = j; p < nparts; p += 16) {
+        a += (double)partials[(size_t)p * 128 + c];
+        b += (double)partials[(size_t)p * 128 + 64 + c];
+    }
+    red[j][0][c] = a;
+    red[j][1][c] = b;
+    __syncthreads();
+    s1 = 0.0; s2 = 0.0;
+    if (j == 0) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { s1 += red[k][0][c]; s2 += red[k][1][c]; }
+    }
+}
+
+// partials: [nparts][2][64] (sum, sum of squares) ; one 1024-thread block, threads 0..63 finish
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ partials, int nparts, double count,
                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                    float* running_mean, float* running_var, long long* num_batches_tracked,
                                    float momentum, float eps, float* scale, float* shift, float* save_mean,
                                    float* save_invstd) {
+    __shared__ double red[16][2][64];
+    double s1, s2;
+    reduce_partials_1024(partials, nparts, s1, s2, red);
+    if (threadIdx.x >= 64) return;
     const int c = threadIdx.x;
-    double s1 = 0.0, s2 = 0.0;
-    for (int p = 0; p < nparts; ++p) {
-        s1 += (double)partials[(size_t)p * 128 + c];
-        s2 += (double)partials[(size_t)p * 128 + 64 + c];
-    }
     const double mean = s1 / count;
     double var = s2 / count - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -98,16 +116,15 @@ __global__ __launch_bounds__(256) void relu_bwd_reduce_kernel(const float* __res
 }
 
 // partials [nparts][2][64] = (sum dz, sum dz*y_raw)  ->  dy = A*dz + Bc + Cc*y ; dgamma ; dbeta
-__global__ void bn_bwd_finalize_kernel(const float* __restrict__ partials, int nparts, double count,
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ partials, int nparts, double count,
                                        const float* __restrict__ gamma, const float* __restrict__ save_mean,
                                        const float* __restrict__ save_invstd, float* A, float* Bc, float* Cc,
                                        float* dgamma, float* dbeta, int accumulate, int eval_mode) {
+    __shared__ double red[16][2][64];
+    double s1, s2;
+    reduce_partials_1024(partials, nparts, s1, s2, red);
+    if (threadIdx.x >= 64) return;
     const int c = threadIdx.x;
-    double s1 = 0.0, s2 = 0.0;
-    for (int p = 0; p < nparts; ++p) {
-        s1 += (double)partials[(size_t)p * 128 + c];
-        s2 += (double)partials[(size_t)p * 128 + 64 + c];
-    }
     const double mu = save_mean[c], is = save_invstd[c], ga = gamma[c];
     const double sxh = (s2 - mu * s1) * is;            // sum dz * yhat
     A[c] = (float)(ga * is);
@@ -127,7 +144,7 @@ extern "C" {
 int wm_bn_finalize(const float* partials, int nparts, double count, const float* gamma, const float* beta,
                    float* running_mean, float* running_var, long long* num_batches_tracked, float momentum, float eps,
                    float* scale, float* shift, float* save_mean, float* save_invstd, hipStream_t stream) {
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(64), 0, stream, partials, nparts, count, gamma, beta,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(1024), 0, stream, partials, nparts, count, gamma, beta,
                        running_mean, running_var, num_batches_tracked, momentum, eps, scale, shift, save_mean, save_invstd);
     WM_CHECK_LAUNCH();
     return 0;
@@ -162,7 +179,7 @@ int wm_relu_bwd_reduce(const float* g, const float* out, const float* y2, float*
 int wm_bn_bwd_finalize(const float* partials, int nparts, double count, const float* gamma, const float* save_mean,
                        const float* save_invstd, float* A, float* Bc, float* Cc, float* dgamma, float* dbeta,
                        int accumulate, int eval_mode, hipStream_t stream) {
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(64), 0, stream, partials, nparts, count, gamma, save_mean,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(1024), 0, stream, partials, nparts, count, gamma, save_mean,
                        save_invstd, A, Bc, Cc, dgamma, dbeta, accumulate, eval_mode);
     WM_CHECK_LAUNCH();
     return 0;

@@ -15,6 +15,14 @@
 #include "wm_common.hpp"
 using namespace wm;
 
+#ifdef WM_STAMP
+// diagnostic build only (-DWM_STAMP): per-wave cycle totals of the kernel's phases
+__device__ unsigned long long* g_wm_stamp = nullptr;
+#define STAMP(var) unsigned long long var = __builtin_amdgcn_s_memtime()
+#else
+#define STAMP(var)
+#endif
+
 namespace {
 
 enum { PRO_NONE = 0, PRO_BNRELU = 1, PRO_ADDVEC = 2, PRO_BNBWD = 3 };
@@ -71,34 +79,27 @@ __global__ __launch_bounds__(256) void conv64_kernel(Conv64Args a) {
     float4 st2[TWO ? NV : 1];
     float hl[HN], hl2[TWO ? HN : 1];
 
+    // Loads are UNCONDITIONAL (addresses clamped into the clip) and the out-of-range masking happens when the tile is
+    // written to LDS: a per-element "load or zero" select makes hipcc branch around every load and drain vmcnt at
+    // each join -- measured 15 K cycles of serialised round trips per tile in the two-tensor variants.
     auto load_tile = [&](int tile) {
         const int b = tile / tilesPerClip, t0 = (tile - b * tilesPerClip) * NT;
         const float* xb = a.x + (size_t)b * 64 * T;
         const float* xb2 = TWO ? a.x2 + (size_t)b * 64 * T : nullptr;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-            const int idx = tid + i * 256, c = idx / QR, q = idx % QR, t = t0 + 4 * q;
-            if (t < T) {
-                st[i] = *reinterpret_cast<const float4*>(xb + (size_t)c * T + t);
-                if (TWO) st2[i] = *reinterpret_cast<const float4*>(xb2 + (size_t)c * T + t);
-            } else {
-                st[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (TWO) st2[i] = st[i];
-            }
+            const int idx = tid + i * 256, c = idx / QR, q = idx % QR;
+            const int t = min(t0 + 4 * q, T - 4);
+            st[i] = *reinterpret_cast<const float4*>(xb + (size_t)c * T + t);
+            if (TWO) st2[i] = *reinterpret_cast<const float4*>(xb2 + (size_t)c * T + t);
         }
 #pragma unroll
         for (int i = 0; i < HN; ++i) {
-            const int idx = tid + i * 256;
-            hl[i] = 0.f;
-            if (TWO) hl2[i] = 0.f;
-            if (idx < HTOT) {
-                const int c = idx / (2 * PAD), h = idx % (2 * PAD);
-                const int t = (h < PAD) ? t0 - PAD + h : t0 + NT + (h - PAD);
-                if (t >= 0 && t < T) {
-                    hl[i] = xb[(size_t)c * T + t];
-                    if (TWO) hl2[i] = xb2[(size_t)c * T + t];
-                }
-            }
+            const int idx = min(tid + i * 256, HTOT - 1);
+            const int c = idx / (2 * PAD), h = idx % (2 * PAD);
+            const int t = min(max((h < PAD) ? t0 - PAD + h : t0 + NT + (h - PAD), 0), T - 1);
+            hl[i] = xb[(size_t)c * T + t];
+            if (TWO) hl2[i] = xb2[(size_t)c * T + t];
         }
     };
     auto write_tile = [&](int tile) {
@@ -111,13 +112,12 @@ __global__ __launch_bounds__(256) void conv64_kernel(Conv64Args a) {
                 const float ca = (PRO == PRO_ADDVEC) ? a.pa[b * 64 + c] : Cs[c];
                 const float cb = Cs[64 + c], cc = Cs[128 + c];
                 const float4 w = TWO ? st2[i] : v;
-                if (t < T) {
-                    v.x = pro_apply<PRO>(v.x, w.x, ca, cb, cc);
-                    v.y = pro_apply<PRO>(v.y, w.y, ca, cb, cc);
-                    v.z = pro_apply<PRO>(v.z, w.z, ca, cb, cc);
-                    v.w = pro_apply<PRO>(v.w, w.w, ca, cb, cc);
-                }
+                v.x = pro_apply<PRO>(v.x, w.x, ca, cb, cc);
+                v.y = pro_apply<PRO>(v.y, w.y, ca, cb, cc);
+                v.z = pro_apply<PRO>(v.z, w.z, ca, cb, cc);
+                v.w = pro_apply<PRO>(v.w, w.w, ca, cb, cc);
             }
+            if (t >= T) v = make_float4(0.f, 0.f, 0.f, 0.f);     // T % 4 == 0: a float4 is all in or all out
             *reinterpret_cast<float4*>(Xs + c * XS + 4 + 4 * q) = v;
         }
 #pragma unroll
@@ -127,10 +127,11 @@ __global__ __launch_bounds__(256) void conv64_kernel(Conv64Args a) {
                 const int c = idx / (2 * PAD), h = idx % (2 * PAD);
                 const int t = (h < PAD) ? t0 - PAD + h : t0 + NT + (h - PAD);
                 float v = hl[i];
-                if (PRO != PRO_NONE && t >= 0 && t < T) {
+                if (PRO != PRO_NONE) {
                     const float ca = (PRO == PRO_ADDVEC) ? a.pa[b * 64 + c] : Cs[c];
                     v = pro_apply<PRO>(v, TWO ? hl2[i] : v, ca, Cs[64 + c], Cs[128 + c]);
                 }
+                if (t < 0 || t >= T) v = 0.f;
                 Xs[c * XS + ((h < PAD) ? 4 - PAD + h : 4 + NT + (h - PAD))] = v;
             }
         }
@@ -159,7 +160,11 @@ __global__ __launch_bounds__(256) void conv64_kernel(Conv64Args a) {
         for (int j = 0; j < 32; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
     }
 
+#ifdef WM_STAMP
+    unsigned long long tm[6] = {0, 0, 0, 0, 0, 0};
+#endif
     while (tile < ntiles) {
+        STAMP(ts0);
         const int next = tile + gridDim.x;
         if (next < ntiles) load_tile(next);           // in flight while the matrix cores work
 
@@ -172,11 +177,12 @@ __global__ __launch_bounds__(256) void conv64_kernel(Conv64Args a) {
                 for (int nt = 0; nt < NN; ++nt)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const int co = mt * 32 + mfma_row(r, half), t = t0 + wave * NTW + nt * 32 + l31;
-                        e1r[(mt * NN + nt) * 16 + r] = (t < T) ? a.e1[((size_t)b * 64 + co) * T + t] : 0.f;
+                        const int co = mt * 32 + mfma_row(r, half), t = min(t0 + wave * NTW + nt * 32 + l31, T - 1);
+                        e1r[(mt * NN + nt) * 16 + r] = a.e1[((size_t)b * 64 + co) * T + t];      // masked at use (t < T)
                     }
         }
 
+        STAMP(ts1);
         f32x16 acc[2][NN];
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
@@ -205,6 +211,7 @@ __global__ __launch_bounds__(256) void conv64_kernel(Conv64Args a) {
             }
         }
 
+        STAMP(ts2);
         // epilogue straight from the accumulators
         float* yb = a.y + (size_t)b * 64 * T;
 #pragma unroll
@@ -231,11 +238,25 @@ __global__ __launch_bounds__(256) void conv64_kernel(Conv64Args a) {
                     }
                 }
 
+        STAMP(ts3);
         __syncthreads();                              // every wave is done with Xs
+        STAMP(ts4);
         if (next < ntiles) write_tile(next);
+        STAMP(ts5);
         __syncthreads();
+        STAMP(ts6);
+#ifdef WM_STAMP
+        tm[0] += ts1 - ts0; tm[1] += ts2 - ts1; tm[2] += ts3 - ts2; tm[3] += ts4 - ts3; tm[4] += ts5 - ts4; tm[5] += ts6 - ts5;
+#endif
         tile = next;
     }
+#ifdef WM_STAMP
+    if (g_wm_stamp && lane == 0) {
+        unsigned long long* d = g_wm_stamp + ((size_t)blockIdx.x * 4 + wave) * 6;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) d[i] = tm[i];
+    }
+#endif
 
     if (STATS) {
         float* red = Xs;                              // [4 waves][2][64]
@@ -335,31 +356,23 @@ __global__ __launch_bounds__(256) void wgrad64_kernel(Wgrad64Args a) {
 #pragma unroll
     for (int i = 0; i < NV; ++i) bsum[i] = 0.f;
 
-    auto load_tile = [&](int tile) {
+    auto load_tile = [&](int tile) {            // branch-free, see conv64_kernel
         const int b = tile / tilesPerClip, t0 = (tile - b * tilesPerClip) * NT;
         const size_t base = (size_t)b * 64 * T;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-            const int idx = tid + i * 256, c = idx / QR, q = idx % QR, t = t0 + 4 * q;
-            if (t < T) {
-                sg[i] = *reinterpret_cast<const float4*>(a.g + base + (size_t)c * T + t);
-                if (GTWO) sg2[i] = *reinterpret_cast<const float4*>(a.g2 + base + (size_t)c * T + t);
-                sx[i] = *reinterpret_cast<const float4*>(a.x + base + (size_t)c * T + t);
-            } else {
-                sg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (GTWO) sg2[i] = sg[i];
-                sx[i] = sg[i];
-            }
+            const int idx = tid + i * 256, c = idx / QR, q = idx % QR;
+            const int t = min(t0 + 4 * q, T - 4);
+            sg[i] = *reinterpret_cast<const float4*>(a.g + base + (size_t)c * T + t);
+            if (GTWO) sg2[i] = *reinterpret_cast<const float4*>(a.g2 + base + (size_t)c * T + t);
+            sx[i] = *reinterpret_cast<const float4*>(a.x + base + (size_t)c * T + t);
         }
 #pragma unroll
         for (int i = 0; i < HN; ++i) {
-            const int idx = tid + i * 256;
-            hx[i] = 0.f;
-            if (idx < HTOT) {
-                const int c = idx / (2 * PAD), h = idx % (2 * PAD);
-                const int t = (h < PAD) ? t0 - PAD + h : t0 + NT + (h - PAD);
-                if (t >= 0 && t < T) hx[i] = a.x[base + (size_t)c * T + t];
-            }
+            const int idx = min(tid + i * 256, HTOT - 1);
+            const int c = idx / (2 * PAD), h = idx % (2 * PAD);
+            const int t = min(max((h < PAD) ? t0 - PAD + h : t0 + NT + (h - PAD), 0), T - 1);
+            hx[i] = a.x[base + (size_t)c * T + t];
         }
     };
     auto write_tile = [&](int tile) {
@@ -368,25 +381,24 @@ __global__ __launch_bounds__(256) void wgrad64_kernel(Wgrad64Args a) {
         for (int i = 0; i < NV; ++i) {
             const int idx = tid + i * 256, c = idx / QR, q = idx % QR, t = t0 + 4 * q;
             float4 v = sg[i], u = sx[i];
-            if (t < T) {
-                if (GPRO == PRO_BNBWD) {
-                    const float ca = Cs[c], cb = Cs[64 + c], cc = Cs[128 + c];
-                    const float4 w = sg2[i];
-                    v.x = pro_apply<PRO_BNBWD>(v.x, w.x, ca, cb, cc);
-                    v.y = pro_apply<PRO_BNBWD>(v.y, w.y, ca, cb, cc);
-                    v.z = pro_apply<PRO_BNBWD>(v.z, w.z, ca, cb, cc);
-                    v.w = pro_apply<PRO_BNBWD>(v.w, w.w, ca, cb, cc);
-                }
-                if (XPRO != PRO_NONE) {
-                    const float ca = (XPRO == PRO_ADDVEC) ? a.xa[b * 64 + c] : Cs[192 + c];
-                    const float cb = Cs[256 + c];
-                    u.x = pro_apply<XPRO>(u.x, 0.f, ca, cb, 0.f);
-                    u.y = pro_apply<XPRO>(u.y, 0.f, ca, cb, 0.f);
-                    u.z = pro_apply<XPRO>(u.z, 0.f, ca, cb, 0.f);
-                    u.w = pro_apply<XPRO>(u.w, 0.f, ca, cb, 0.f);
-                }
-                bsum[i] += (v.x + v.y) + (v.z + v.w);
+            if (GPRO == PRO_BNBWD) {
+                const float ca = Cs[c], cb = Cs[64 + c], cc = Cs[128 + c];
+                const float4 w = sg2[i];
+                v.x = pro_apply<PRO_BNBWD>(v.x, w.x, ca, cb, cc);
+                v.y = pro_apply<PRO_BNBWD>(v.y, w.y, ca, cb, cc);
+                v.z = pro_apply<PRO_BNBWD>(v.z, w.z, ca, cb, cc);
+                v.w = pro_apply<PRO_BNBWD>(v.w, w.w, ca, cb, cc);
             }
+            if (XPRO != PRO_NONE) {
+                const float ca = (XPRO == PRO_ADDVEC) ? a.xa[b * 64 + c] : Cs[192 + c];
+                const float cb = Cs[256 + c];
+                u.x = pro_apply<XPRO>(u.x, 0.f, ca, cb, 0.f);
+                u.y = pro_apply<XPRO>(u.y, 0.f, ca, cb, 0.f);
+                u.z = pro_apply<XPRO>(u.z, 0.f, ca, cb, 0.f);
+                u.w = pro_apply<XPRO>(u.w, 0.f, ca, cb, 0.f);
+            }
+            if (t >= T) { v = make_float4(0.f, 0.f, 0.f, 0.f); u = v; }
+            bsum[i] += (v.x + v.y) + (v.z + v.w);
             *reinterpret_cast<float4*>(Gs + c * GS + 4 * q) = v;
             *reinterpret_cast<float4*>(Xs + c * XS + 4 + 4 * q) = u;
         }
@@ -397,10 +409,11 @@ __global__ __launch_bounds__(256) void wgrad64_kernel(Wgrad64Args a) {
                 const int c = idx / (2 * PAD), h = idx % (2 * PAD);
                 const int t = (h < PAD) ? t0 - PAD + h : t0 + NT + (h - PAD);
                 float v = hx[i];
-                if (XPRO != PRO_NONE && t >= 0 && t < T) {
+                if (XPRO != PRO_NONE) {
                     const float ca = (XPRO == PRO_ADDVEC) ? a.xa[b * 64 + c] : Cs[192 + c];
                     v = pro_apply<XPRO>(v, 0.f, ca, Cs[256 + c], 0.f);
                 }
+                if (t < 0 || t >= T) v = 0.f;
                 Xs[c * XS + ((h < PAD) ? 4 - PAD + h : 4 + NT + (h - PAD))] = v;
             }
         }
@@ -546,6 +559,12 @@ __global__ void wgrad64_reduce_kernel(const float* __restrict__ partial, int npa
 // C ABI
 // =============================================================================================
 extern "C" {
+
+#ifdef WM_STAMP
+int wm_debug_set_stamp_buffer(unsigned long long* buf) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_wm_stamp), &buf, sizeof(buf));
+}
+#endif
 
 int wm_pack_w64(const float* w, float* wp, int KW, int mode, hipStream_t stream) {
     if ((KW != 3 && KW != 7) || mode < 0 || mode > 3) return (int)hipErrorInvalidValue;

@@ -34,6 +34,38 @@ __device__ __forceinline__ float half_wave_sum(float v) {
     for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o);
     return v;
 }
+// Transposing butterfly: every lane brings 32 values x[0..31]; on return lane l of each 32-lane half-wave holds
+// the sum over that half-wave of x[l & 31].  31 shuffles instead of the 160 of 32 independent tree reductions,
+// and the 5 stages are 16/8/4/2/1 independent shuffles wide, so they pipeline.
+__device__ __forceinline__ float half_wave_transpose_sum32(float (&x)[32], int lane) {
+#pragma unroll
+    for (int s = 4; s >= 0; --s) {
+        const int h = 1 << s;
+        const bool up = (lane >> s) & 1;
+#pragma unroll
+        for (int i = 0; i < h; ++i) {
+            const float keep = up ? x[i + h] : x[i];
+            const float send = up ? x[i] : x[i + h];
+            x[i] = keep + __shfl_xor(send, h);
+        }
+    }
+    return x[0];
+}
+// 16-value variant: on return every lane l holds the half-wave total of x[l & 15]
+__device__ __forceinline__ float half_wave_transpose_sum16(float (&x)[16], int lane) {
+#pragma unroll
+    for (int s = 3; s >= 0; --s) {
+        const int h = 1 << s;
+        const bool up = (lane >> s) & 1;
+#pragma unroll
+        for (int i = 0; i < h; ++i) {
+            const float keep = up ? x[i + h] : x[i];
+            const float send = up ? x[i] : x[i + h];
+            x[i] = keep + __shfl_xor(send, h);
+        }
+    }
+    return x[0] + __shfl_xor(x[0], 16);
+}
 __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);

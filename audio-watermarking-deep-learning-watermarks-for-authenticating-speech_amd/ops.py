@@ -109,7 +109,7 @@ class ResBlockFn(torch.autograd.Function):
         stats = _f32(NCU * 128, device=dev)
         lib.wm_conv64(_p(dz2), _p(y2), _p(wp2d), _p(k2[0]), _p(k2[1]), _p(k2[2]), None, _p(y1), _p(sc1), _p(sh1), _p(dz1), _p(stats),
                       B, T, 3, 3, 1, st)
-        wpart = _f32(NCU * (3 * 4096 + 64), device=dev)
+        wpart = _f32(2 * NCU * (3 * 4096 + 64), device=dev)
         dw2, db2 = torch.empty_like(w2), _f32(64, device=dev)
         lib.wm_wgrad64(_p(dz2), _p(y2), _p(k2[0]), _p(k2[1]), _p(k2[2]), _p(y1), _p(sc1), _p(sh1), _p(wpart), _p(dw2), _p(db2),
                        B, T, 3, 3, 1, 0, 0, st)
@@ -291,7 +291,7 @@ class ConvT7Fn(torch.autograd.Function):
         wpd = pack_w64(w, 7, 3)
         dx = torch.empty_like(x)
         lib.wm_conv64(_p(g), None, _p(wpd), None, None, None, None, None, None, None, _p(dx), None, B, T, 7, 0, 3, st)
-        part = _f32(NCU * (7 * 4096 + 64), device=dev)
+        part = _f32(2 * NCU * (7 * 4096 + 64), device=dev)
         dw, db = torch.empty_like(w), _f32(64, device=dev)
         lib.wm_wgrad64(_p(g), None, None, None, None, _p(x), _p(vec), None, _p(part), _p(dw), _p(db), B, T, 7, 0,
                        2 if vec is not None else 0, 1, 0, st)

@@ -42,7 +42,7 @@ int wm_conv64(const float* x, const float* x2, const float* wp, const float* pa,
               const float* bias, const float* e1, const float* ea, const float* eb, float* y, float* stats,
               int B, int T, int KW, int pro, int epi, wm_stream_t stream);
 
-/* dW (+)= sum_{b,t} gpro(g)[out,t] * xpro(x)[in,t+tap-KW/2]; dbias (+)= sum gpro(g).  partial: [256][KW*4096+64].
+/* dW (+)= sum_{b,t} gpro(g)[out,t] * xpro(x)[in,t+tap-KW/2]; dbias (+)= sum gpro(g).  partial: [512][KW*4096+64].
  *   gpro 0|3, xpro 0|1|2 as above; layout 0: Conv1d weight [out][in][KW], 1: ConvTranspose1d weight [in][out][KW]. */
 int wm_wgrad64(const float* g, const float* g2, const float* ga, const float* gb, const float* gc,
                const float* x, const float* xa, const float* xb, float* partial, float* dw, float* dbias,

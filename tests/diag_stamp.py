@@ -1,0 +1,31 @@
+"""diagnostic: where a conv64 workgroup spends its cycles (needs the -DWM_STAMP build libwm_hip_stamp.so)"""
+import ctypes, os, sys, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+so = os.path.join(ROOT, "audio-watermarking-deep-learning-watermarks-for-authenticating-speech_amd", "libwm_hip_stamp.so")
+L = ctypes.CDLL(so)
+dev = torch.device("cuda:0"); B, T = 256, 16000
+x = torch.randn(B, 64, T, device=dev); y = torch.empty_like(x); x2 = torch.randn(B, 64, T, device=dev); x3 = torch.randn(B, 64, T, device=dev)
+w = torch.randn(64, 64, 3, device=dev) * 0.05; wp = torch.empty(3 * 4096, device=dev); bias = torch.randn(64, device=dev)
+c = [torch.rand(64, device=dev) for _ in range(5)]
+stats = torch.empty(256 * 128, device=dev)
+buf = torch.zeros(256 * 4 * 6, dtype=torch.int64, device=dev)
+vp = ctypes.c_void_p
+L.wm_debug_set_stamp_buffer(vp(buf.data_ptr()))
+L.wm_pack_w64(vp(w.data_ptr()), vp(wp.data_ptr()), 3, 0, None)
+def run(name, pro, epi, st):
+    args = [vp(x.data_ptr()), vp(x2.data_ptr()) if pro == 3 else None, vp(wp.data_ptr()),
+            vp(c[0].data_ptr()), vp(c[1].data_ptr()), vp(c[2].data_ptr()), vp(bias.data_ptr()),
+            vp(x3.data_ptr()) if epi in (1, 2) else None, vp(c[3].data_ptr()), vp(c[4].data_ptr()), vp(y.data_ptr()),
+            vp(stats.data_ptr()) if st else None, B, T, 3, pro, epi, None]
+    for _ in range(2):
+        buf.zero_(); rc = L.wm_conv64(*args); torch.cuda.synchronize()
+    assert rc == 0, rc
+    d = buf.view(256, 4, 6).double().mean(dim=(0, 1))
+    names = ["load-issue+e1", "mfma", "epilogue", "bar1", "lds-write", "bar2"]
+    print(f"{name:28s} " + "  ".join(f"{n} {v:9.0f}" for n, v in zip(names, d)) + f"   total {d.sum():9.0f}")
+run("fwd none/bias", 0, 0, False)
+run("fwd none/bias +stats", 0, 0, True)
+run("fwd bnrelu/bias +stats", 1, 0, True)
+run("dgrad bnbwd/relumask +stats", 3, 1, True)
+run("dgrad bnbwd/add", 3, 2, False)
+run("dgrad bnbwd/none", 3, 3, False)
