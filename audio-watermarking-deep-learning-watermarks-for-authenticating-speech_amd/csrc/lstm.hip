@@ -22,6 +22,19 @@ using namespace wm;
 
 namespace {
 
+// Per-step tensors (xp / gates / da) are stored [B][T][256] with the column order  n' = unit*4 + gate  so that the
+// four gates of a hidden unit sit in four adjacent lanes (one DPP quad) of the recurrence kernels and every per-step
+// access of a wave is one contiguous 256-B segment.  gate row of the PyTorch parameters: n = gate*64 + unit.
+__device__ __forceinline__ int gate_row(int np) { return (np & 3) * 64 + (np >> 2); }
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+// broadcast lane k of every quad (DPP quad_perm: no LDS round trip, unlike ds_bpermute)
+template <int K>
+__device__ __forceinline__ float quad_bcast(float v) {
+    constexpr int ctrl = K | (K << 2) | (K << 4) | (K << 6);
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, 0xf, 0xf, false));
+}
+
 // ------------------------------------------------------------------------------------ xproj
 // block = (clip, 128-step tile); wave w owns gate columns [64w, 64w+64); D rows = time, cols = gate.
 __global__ __launch_bounds__(256) void lstm_xproj_kernel(const float* __restrict__ x, const float* __restrict__ w_ih,
@@ -35,19 +48,21 @@ __global__ __launch_bounds__(256) void lstm_xproj_kernel(const float* __restrict
     const float* xb = x + (size_t)b * 64 * T;
     for (int i = tid; i < 64 * (NT / 4); i += 256) {
         const int c = i / (NT / 4), q = i % (NT / 4), t = t0 + 4 * q;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (t < T) v = *reinterpret_cast<const float4*>(xb + (size_t)c * T + t);
-        *reinterpret_cast<float4*>(xs + c * XS + 4 * q) = v;
+        // unconditional load from a clamped address (rows past T are never stored): no branch, no vmcnt drain
+        *reinterpret_cast<float4*>(xs + c * XS + 4 * q) = *reinterpret_cast<const float4*>(xb + (size_t)c * T + min(t, T - 4));
     }
     // B operand (W_ih^T) for this wave's two 32-column tiles: B[k = c][j = n] = w_ih[n][c]
     float breg[2][32];
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-        for (int s = 0; s < 32; ++s) breg[nt][s] = w_ih[(wave * 64 + nt * 32 + l31) * 64 + 2 * s + half];
+        for (int s = 0; s < 32; ++s) breg[nt][s] = w_ih[gate_row(wave * 64 + nt * 32 + l31) * 64 + 2 * s + half];
     float bias[2];
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) bias[nt] = b_ih[wave * 64 + nt * 32 + l31] + b_hh[wave * 64 + nt * 32 + l31];
+    for (int nt = 0; nt < 2; ++nt) {
+        const int n = gate_row(wave * 64 + nt * 32 + l31);
+        bias[nt] = b_ih[n] + b_hh[n];
+    }
     __syncthreads();
 #pragma unroll 1
     for (int mt = 0; mt < 4; ++mt) {
@@ -90,17 +105,21 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(const float* xp, const fl
                                                        float* __restrict__ cst, int T) {
     __shared__ __align__(16) float hs[2][64];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int q = lane >> 4, ul = lane & 15, u = wave * 16 + ul, n = q * 64 + u;
-    float wr[64];
+    const int q = lane & 3, ul = lane >> 2, u = wave * 16 + ul, n = q * 64 + u, np = wave * 64 + lane;
+    // one W_hh row per lane, as 32 register pairs: the recurrent dot product issues v_pk_fma_f32, which keeps the
+    // SIMD's fp32 pipe full from a single wave (a lone wave issues one VALU op per 4 cycles; a plain v_fma only
+    // occupies the pipe for 2 of them)
+    v2f wr[32];
 #pragma unroll
     for (int k = 0; k < 64; k += 4) {
         const float4 v = *reinterpret_cast<const float4*>(w_hh + n * 64 + k);
-        wr[k] = v.x; wr[k + 1] = v.y; wr[k + 2] = v.z; wr[k + 3] = v.w;
+        wr[k / 2] = v2f{v.x, v.y};
+        wr[k / 2 + 1] = v2f{v.z, v.w};
     }
     if (tid < 128) (&hs[0][0])[tid] = 0.f;
     float c = 0.f;
-    const float* xpb = xp + (size_t)b * T * 256 + n;
-    float* gb = SAVE ? gates + (size_t)b * T * 256 + n : nullptr;
+    const float* xpb = xp + (size_t)b * T * 256 + np;
+    float* gb = SAVE ? gates + (size_t)b * T * 256 + np : nullptr;
     float* cb = SAVE ? cst + (size_t)b * T * 64 + u : nullptr;
     float* hb = hout + ((size_t)b * 64 + u) * T;
     const bool is_g = (q == 2);
@@ -108,7 +127,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(const float* xp, const fl
     float xa[16], xb_[16];
     auto prefetch = [&](float (&buf)[16], int t0) {
 #pragma unroll
-        for (int s = 0; s < 16; ++s) buf[s] = (t0 + s < T) ? xpb[(size_t)(t0 + s) * 256] : 0.f;
+        for (int s = 0; s < 16; ++s) buf[s] = xpb[(size_t)min(t0 + s, T - 1) * 256];      // unconditional (clamped)
     };
     auto run_chunk = [&](const float (&xin)[16], int t0) {
         float hk[4];
@@ -117,33 +136,29 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(const float* xp, const fl
             const int t = t0 + s;
             if (t < T) {                                   // uniform across the workgroup
                 const float4* hp = reinterpret_cast<const float4*>(hs[s & 1]);
-                float a0 = xin[s], a1 = 0.f, a2 = 0.f, a3 = 0.f;
+                v2f a01 = v2f{xin[s], 0.f}, a23 = v2f{0.f, 0.f}, b01 = a23, b23 = a23;
 #pragma unroll
-                for (int k = 0; k < 16; k += 4) {
-                    const float4 h0 = hp[k], h1 = hp[k + 1], h2 = hp[k + 2], h3 = hp[k + 3];
-                    a0 = fmaf(wr[4 * k + 0], h0.x, a0); a1 = fmaf(wr[4 * k + 1], h0.y, a1);
-                    a2 = fmaf(wr[4 * k + 2], h0.z, a2); a3 = fmaf(wr[4 * k + 3], h0.w, a3);
-                    a0 = fmaf(wr[4 * k + 4], h1.x, a0); a1 = fmaf(wr[4 * k + 5], h1.y, a1);
-                    a2 = fmaf(wr[4 * k + 6], h1.z, a2); a3 = fmaf(wr[4 * k + 7], h1.w, a3);
-                    a0 = fmaf(wr[4 * k + 8], h2.x, a0); a1 = fmaf(wr[4 * k + 9], h2.y, a1);
-                    a2 = fmaf(wr[4 * k + 10], h2.z, a2); a3 = fmaf(wr[4 * k + 11], h2.w, a3);
-                    a0 = fmaf(wr[4 * k + 12], h3.x, a0); a1 = fmaf(wr[4 * k + 13], h3.y, a1);
-                    a2 = fmaf(wr[4 * k + 14], h3.z, a2); a3 = fmaf(wr[4 * k + 15], h3.w, a3);
+                for (int k = 0; k < 16; k += 2) {
+                    const float4 h0 = hp[k], h1 = hp[k + 1];
+                    a01 = __builtin_elementwise_fma(wr[2 * k], v2f{h0.x, h0.y}, a01);
+                    a23 = __builtin_elementwise_fma(wr[2 * k + 1], v2f{h0.z, h0.w}, a23);
+                    b01 = __builtin_elementwise_fma(wr[2 * k + 2], v2f{h1.x, h1.y}, b01);
+                    b23 = __builtin_elementwise_fma(wr[2 * k + 3], v2f{h1.z, h1.w}, b23);
                 }
-                const float act = gate_act((a0 + a1) + (a2 + a3), is_g);
-                const float gi = __shfl(act, ul), gf = __shfl(act, ul + 16), gg = __shfl(act, ul + 32), go = __shfl(act, ul + 48);
+                const v2f sm = (a01 + a23) + (b01 + b23);
+                const float act = gate_act(sm.x + sm.y, is_g);
+                const float gi = quad_bcast<0>(act), gf = quad_bcast<1>(act), gg = quad_bcast<2>(act), go = quad_bcast<3>(act);
                 c = fmaf(gf, c, gi * gg);
                 const float h = go * tanh_s(c);
                 if (q == 0) hs[(s + 1) & 1][u] = h;
                 if (SAVE) {
-                    gb[(size_t)t * 256] = act;
+                    gb[(size_t)t * 256] = act;             // one contiguous 256-B segment per wave
                     if (q == 1) cb[(size_t)t * 64] = c;
                 }
                 if (((s >> 2) & 3) == q) hk[s & 3] = h;
-                if ((s & 3) == 3 && (s >> 2) == 3) {
+                if (s == 15) {
                     // every lane now holds h for steps t0+4q .. t0+4q+3 of its unit
-                    const int tq = t0 + 4 * q;
-                    if (tq + 3 < T) *reinterpret_cast<float4*>(hb + tq) = make_float4(hk[0], hk[1], hk[2], hk[3]);
+                    *reinterpret_cast<float4*>(hb + t0 + 4 * q) = make_float4(hk[0], hk[1], hk[2], hk[3]);
                 }
                 __syncthreads();
             }
@@ -168,42 +183,40 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(const float* xp, const fl
 }
 
 // ------------------------------------------------------------------------------- recurrence bwd
-// gates: in = saved activations (i,f,g,o), out = pre-activation gradients da  [B,T,256]
+// gates: in = saved activations, out = pre-activation gradients da  [B,T,256] (column order n' = unit*4 + gate)
 __global__ __launch_bounds__(256) void lstm_bwd_kernel(float* __restrict__ gates, const float* __restrict__ cst,
                                                        const float* __restrict__ dh_out, const float* __restrict__ w_hh,
                                                        int T) {
     __shared__ __align__(16) float das[4][64];      // wave-private da vectors
     __shared__ __align__(16) float part[2][64][4];  // [buffer][k][wave] partial dh
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int q = lane >> 4, ul = lane & 15, u = wave * 16 + ul, n = q * 64 + u;
-    // transposed-product operand: lane = output k, register j = row held by lane j of this wave
-    float wt[64];
+    const int q = lane & 3, ul = lane >> 2, u = wave * 16 + ul, np = wave * 64 + lane;
+    // transposed-product operand: lane = output k, register j = the gate row held by lane j of this wave
+    v2f wt[32];
 #pragma unroll
-    for (int j = 0; j < 64; ++j) wt[j] = w_hh[((j >> 4) * 64 + wave * 16 + (j & 15)) * 64 + lane];
+    for (int j = 0; j < 64; j += 2)
+        wt[j / 2] = v2f{w_hh[((j & 3) * 64 + wave * 16 + (j >> 2)) * 64 + lane],
+                        w_hh[(((j + 1) & 3) * 64 + wave * 16 + ((j + 1) >> 2)) * 64 + lane]};
     if (tid < 512 / 4) reinterpret_cast<float4*>(&part[0][0][0])[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
     float dc = 0.f;
-    float* gb = gates + (size_t)b * T * 256;
+    float* gb = gates + (size_t)b * T * 256 + np;
     const float* cb = cst + (size_t)b * T * 64 + u;
     const float* dhb = dh_out + ((size_t)b * 64 + u) * T;
 
     constexpr int CH = 8;
-    struct Buf { float gi[CH], gf[CH], gg[CH], go[CH], cc[CH + 1], dh[CH]; };
+    struct Buf { float ga[CH], cc[CH + 1], dh[CH]; };
     Buf A, Bf;
-    // chunk covers steps t1-CH+1 .. t1 (descending); cc[j] = c_{t1-CH+j} so cc[CH] = c_{t1}
+    // chunk covers steps t1-CH+1 .. t1 (descending); cc[j] = c_{t1-CH+j} so cc[CH] = c_{t1}.  Loads are unconditional
+    // (clamped indices); steps with t < 0 are never executed and c_{-1} is selected to 0 at use.
     auto prefetch = [&](Buf& f, int t1) {
 #pragma unroll
         for (int j = 0; j < CH; ++j) {
-            const int t = t1 - CH + 1 + j;
-            const bool ok = (t >= 0);
-            const float* gp = gb + (size_t)(ok ? t : 0) * 256 + u;
-            f.gi[j] = ok ? gp[0] : 0.f; f.gf[j] = ok ? gp[64] : 0.f; f.gg[j] = ok ? gp[128] : 0.f; f.go[j] = ok ? gp[192] : 0.f;
-            f.dh[j] = ok ? dhb[t] : 0.f;
+            const int t = max(t1 - CH + 1 + j, 0);
+            f.ga[j] = gb[(size_t)t * 256];
+            f.dh[j] = dhb[t];
         }
 #pragma unroll
-        for (int j = 0; j <= CH; ++j) {
-            const int t = t1 - CH + j;
-            f.cc[j] = (t >= 0) ? cb[(size_t)t * 64] : 0.f;
-        }
+        for (int j = 0; j <= CH; ++j) f.cc[j] = cb[(size_t)max(t1 - CH + j, 0) * 64];
     };
     int pb = 0;   // partial buffer parity
     auto run_chunk = [&](const Buf& f, int t1) {
@@ -213,27 +226,30 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(float* __restrict__ gates
             if (t >= 0) {
                 const float4 p = *reinterpret_cast<const float4*>(&part[pb][u][0]);
                 const float dht = f.dh[j] + ((p.x + p.y) + (p.z + p.w));
-                const float gi = f.gi[j], gf = f.gf[j], gg = f.gg[j], go = f.go[j];
+                const float act = f.ga[j];
+                const float gi = quad_bcast<0>(act), gf = quad_bcast<1>(act), gg = quad_bcast<2>(act), go = quad_bcast<3>(act);
                 const float tc = tanh_s(f.cc[j + 1]);
+                const float cprev = (t >= 1) ? f.cc[j] : 0.f;
                 const float dct = fmaf(dht * go, 1.f - tc * tc, dc);
                 float da;
                 if (q == 0) da = dct * gg * gi * (1.f - gi);
-                else if (q == 1) da = dct * f.cc[j] * gf * (1.f - gf);
+                else if (q == 1) da = dct * cprev * gf * (1.f - gf);
                 else if (q == 2) da = dct * gi * (1.f - gg * gg);
                 else da = dht * tc * go * (1.f - go);
                 dc = dct * gf;
-                gb[(size_t)t * 256 + n] = da;
+                gb[(size_t)t * 256] = da;
                 das[wave][lane] = da;                       // same wave reads it back: no barrier needed
                 __builtin_amdgcn_wave_barrier();
                 const float4* dp = reinterpret_cast<const float4*>(das[wave]);
-                float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+                v2f a01 = v2f{0.f, 0.f}, a23 = a01;
 #pragma unroll
                 for (int k = 0; k < 16; ++k) {
                     const float4 d = dp[k];
-                    a0 = fmaf(wt[4 * k], d.x, a0); a1 = fmaf(wt[4 * k + 1], d.y, a1);
-                    a2 = fmaf(wt[4 * k + 2], d.z, a2); a3 = fmaf(wt[4 * k + 3], d.w, a3);
+                    a01 = __builtin_elementwise_fma(wt[2 * k], v2f{d.x, d.y}, a01);
+                    a23 = __builtin_elementwise_fma(wt[2 * k + 1], v2f{d.z, d.w}, a23);
                 }
-                part[pb ^ 1][lane][wave] = (a0 + a1) + (a2 + a3);
+                const v2f sm = a01 + a23;
+                part[pb ^ 1][lane][wave] = sm.x + sm.y;
                 pb ^= 1;
                 __syncthreads();
             }
@@ -260,12 +276,12 @@ __global__ __launch_bounds__(256) void lstm_dx_kernel(const float* __restrict__ 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
     const int tilesPerClip = (T + NT - 1) / NT;
     const int b = blockIdx.x / tilesPerClip, t0 = (blockIdx.x % tilesPerClip) * NT;
-    for (int i = tid; i < 256 * 16; i += 256) reinterpret_cast<float4*>(ws)[i] = reinterpret_cast<const float4*>(w_ih)[i];
+    for (int i = tid; i < 256 * 16; i += 256)      // row n' of the LDS image = parameter row gate_row(n')
+        reinterpret_cast<float4*>(ws)[i] = reinterpret_cast<const float4*>(w_ih)[gate_row(i >> 4) * 16 + (i & 15)];
     const float* dab = da + ((size_t)b * T + t0) * 256;
     for (int i = tid; i < NT * 64; i += 256) {
         const int tt = i >> 6, q4 = i & 63;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (t0 + tt < T) v = reinterpret_cast<const float4*>(dab)[i];
+        const float4 v = reinterpret_cast<const float4*>(dab)[min(t0 + tt, T - 1) * 64 - t0 * 64 + q4];   // clamped row; results past T are not stored
         float* d = ds + tt * DS + 4 * q4;
         d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
     }
@@ -310,17 +326,18 @@ __global__ __launch_bounds__(256) void lstm_wgrad_kernel(const float* __restrict
         __syncthreads();
         const float* dab = da + ((size_t)b * T + t0) * 256;
         for (int i = tid; i < NT * 64; i += 256) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (t0 + (i >> 6) < T) v = reinterpret_cast<const float4*>(dab)[i];
+            const int tt = i >> 6;
+            float4 v = reinterpret_cast<const float4*>(dab)[min(t0 + tt, T - 1) * 64 - t0 * 64 + (i & 63)];   // branch-free
+            if (t0 + tt >= T) v = make_float4(0.f, 0.f, 0.f, 0.f);
             reinterpret_cast<float4*>(ds)[i] = v;
         }
         for (int i = tid; i < 128 * NT; i += 256) {
             const int j = i / NT, tt = i % NT, t = t0 + tt;
-            float v = 0.f;
-            if (t < T) {
-                if (j < 64) v = x[((size_t)b * 64 + j) * T + t];
-                else if (t >= 1) v = h[((size_t)b * 64 + (j - 64)) * T + t - 1];
-            }
+            // rows 0..63: x[j][t];  rows 64..127: h[j-64][t-1] (zero initial state at t = 0); clamped address + select
+            const float* src = (j < 64) ? x + ((size_t)b * 64 + j) * T : h + ((size_t)b * 64 + (j - 64)) * T - 1;
+            const int tc = min(max(t, (j < 64) ? 0 : 1), T - 1);
+            float v = src[tc];
+            if (t >= T || (j >= 64 && t < 1)) v = 0.f;
             zs[j * ZS + tt] = v;
         }
         __syncthreads();
@@ -358,11 +375,11 @@ __global__ void lstm_wgrad_reduce_kernel(const float* __restrict__ partial, int 
     float s = 0.f;
     for (int p = 0; p < nparts; ++p) s += partial[(size_t)p * stride + i];
     if (i < 256 * 128) {
-        const int n = i >> 7, j = i & 127;
+        const int n = gate_row(i >> 7), j = i & 127;
         float* dst = (j < 64) ? dw_ih + n * 64 + j : dw_hh + n * 64 + (j - 64);
         *dst = accumulate ? *dst + s : s;
     } else {
-        const int n = i - 256 * 128;
+        const int n = gate_row(i - 256 * 128);
         db_ih[n] = accumulate ? db_ih[n] + s : s;
         db_hh[n] = accumulate ? db_hh[n] + s : s;
     }

@@ -75,18 +75,20 @@ __global__ __launch_bounds__(256) void stem_bwd_kernel(const float* __restrict__
         __syncthreads();
         for (int i = tid; i < 64 * (NT / 4); i += 256) {
             const int c = i / (NT / 4), q = i % (NT / 4), t = t0 + 4 * q;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (t < T) v = *reinterpret_cast<const float4*>(gb + (size_t)c * T + t);
+            float4 v = *reinterpret_cast<const float4*>(gb + (size_t)c * T + min(t, T - 4));   // branch-free load, masked below
+            if (t >= T) v = make_float4(0.f, 0.f, 0.f, 0.f);
             *reinterpret_cast<float4*>(gs + c * GS + 4 + 4 * q) = v;
         }
         for (int i = tid; i < 64 * 6; i += 256) {
             const int c = i / 6, h = i % 6;
             const int t = (h < 3) ? t0 - 3 + h : t0 + NT + (h - 3);
-            gs[c * GS + ((h < 3) ? 1 + h : 4 + NT + (h - 3))] = (t >= 0 && t < T) ? gb[(size_t)c * T + t] : 0.f;
+            const float gv = gb[(size_t)c * T + min(max(t, 0), T - 1)];
+            gs[c * GS + ((h < 3) ? 1 + h : 4 + NT + (h - 3))] = (t >= 0 && t < T) ? gv : 0.f;
         }
         for (int i = tid; i < NT + 6; i += 256) {
             const int t = t0 - 3 + i;
-            ss[i] = (t >= 0 && t < T) ? s[(size_t)b * T + t] : 0.f;
+            const float sv = s[(size_t)b * T + min(max(t, 0), T - 1)];
+            ss[i] = (t >= 0 && t < T) ? sv : 0.f;
         }
         __syncthreads();
         if (ds) {
@@ -251,11 +253,15 @@ __global__ __launch_bounds__(256) void headN_bwd_kernel(const float* __restrict_
         const int nt = min(256, T - t0);
         __syncthreads();
         const float* gb = g + ((size_t)b * T + t0) * NO;
-        for (int i = tid; i < 256 * NO; i += 256) gsm[(i / NO) * GS + (i % NO)] = (i < nt * NO) ? gb[i] : 0.f;
+        for (int i = tid; i < 256 * NO; i += 256) {
+            const float gv = gb[min(i, nt * NO - 1)];                 // branch-free load, masked by the select
+            gsm[(i / NO) * GS + (i % NO)] = (i < nt * NO) ? gv : 0.f;
+        }
         const float* xb = x + (size_t)b * 64 * T + t0;
         for (int i = tid; i < 64 * 256; i += 256) {
             const int c = i >> 8, tt = i & 255;
-            xs[c * XS + tt] = (tt < nt) ? xb[(size_t)c * T + tt] : 0.f;
+            const float xv = xb[(size_t)c * T + min(tt, nt - 1)];
+            xs[c * XS + tt] = (tt < nt) ? xv : 0.f;
         }
         __syncthreads();
         // ---- dx tile: D[c][t]
