@@ -266,51 +266,76 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(float* __restrict__ gates
 }
 
 // ------------------------------------------------------------------------------------ dx GEMM
-// dx[b,c,t] = sum_n da[b,t,n] w_ih[n][c] ;  block = (clip, 64-step tile); wave = (c half, t half)
+// dx[b,c,t] = sum_n da[b,t,n'] w_ih[gate_row(n')][c] ;  persistent blocks over (clip, 64-step) tiles, the next da
+// tile is fetched into registers while the matrix cores work on the current one; wave = (c half, t half)
 __global__ __launch_bounds__(256) void lstm_dx_kernel(const float* __restrict__ da, const float* __restrict__ w_ih,
-                                                      float* __restrict__ dx, int T) {
+                                                      float* __restrict__ dx, int B, int T) {
     constexpr int NT = 64, DS = 257;
     extern __shared__ __align__(16) float smem[];
-    float* ws = smem;               // [256][64]  A[i = c][k = n] = w_ih[n][c]
-    float* ds = smem + 256 * 64;    // [NT][DS]   B[k = n][j = t] = da[t][n]
+    float* ws = smem;               // [256][64]  A[i = c][k = n'] = w_ih[gate_row(n')][c]
+    float* ds = smem + 256 * 64;    // [NT][DS]   B[k = n'][j = t] = da[t][n']
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
-    const int tilesPerClip = (T + NT - 1) / NT;
-    const int b = blockIdx.x / tilesPerClip, t0 = (blockIdx.x % tilesPerClip) * NT;
+    const int tilesPerClip = (T + NT - 1) / NT, ntiles = B * tilesPerClip;
     for (int i = tid; i < 256 * 16; i += 256)      // row n' of the LDS image = parameter row gate_row(n')
         reinterpret_cast<float4*>(ws)[i] = reinterpret_cast<const float4*>(w_ih)[gate_row(i >> 4) * 16 + (i & 15)];
-    const float* dab = da + ((size_t)b * T + t0) * 256;
-    for (int i = tid; i < NT * 64; i += 256) {
-        const int tt = i >> 6, q4 = i & 63;
-        const float4 v = reinterpret_cast<const float4*>(dab)[min(t0 + tt, T - 1) * 64 - t0 * 64 + q4];   // clamped row; results past T are not stored
-        float* d = ds + tt * DS + 4 * q4;
-        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-    }
+    float4 st[16];
+    auto load_tile = [&](int tile) {               // branch-free: rows past T read a clamped row, never stored
+        const int b = tile / tilesPerClip, t0 = (tile % tilesPerClip) * NT;
+        const float4* dab = reinterpret_cast<const float4*>(da + (size_t)b * T * 256);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int i = tid + k * 256;
+            st[k] = dab[(size_t)min(t0 + (i >> 6), T - 1) * 64 + (i & 63)];
+        }
+    };
+    auto write_tile = [&]() {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int i = tid + k * 256;
+            float* d = ds + (i >> 6) * DS + 4 * (i & 63);
+            d[0] = st[k].x; d[1] = st[k].y; d[2] = st[k].z; d[3] = st[k].w;
+        }
+    };
+    int tile = blockIdx.x;
+    if (tile < ntiles) load_tile(tile);
+    __syncthreads();
+    if (tile < ntiles) write_tile();
     __syncthreads();
     const int mt = wave & 1, nt = wave >> 1;
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     const float* ap = ws + half * 64 + mt * 32 + l31;
     const float* bp = ds + (nt * 32 + l31) * DS + half;
-#pragma unroll 8
-    for (int s = 0; s < 128; ++s) acc = mfma32(ap[2 * s * 64], bp[2 * s], acc);
+    while (tile < ntiles) {
+        const int next = tile + gridDim.x;
+        if (next < ntiles) load_tile(next);
+        f32x16 acc;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int c = mt * 32 + mfma_row(r, half), t = t0 + nt * 32 + l31;
-        if (t < T) dx[((size_t)b * 64 + c) * T + t] = acc[r];
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll 8
+        for (int s = 0; s < 128; ++s) acc = mfma32(ap[2 * s * 64], bp[2 * s], acc);
+        const int b = tile / tilesPerClip, t0 = (tile % tilesPerClip) * NT;
+        const int t = t0 + nt * 32 + l31;
+        if (t < T) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dx[((size_t)b * 64 + mt * 32 + mfma_row(r, half)) * T + t] = acc[r];
+        }
+        __syncthreads();
+        if (next < ntiles) write_tile();
+        __syncthreads();
+        tile = next;
     }
 }
 
 // ---------------------------------------------------------------------------------- wgrad GEMM
-// G[n][j] = sum_{b,t} da[b,t,n] * z[b,j,t],  z = [x (64 rows) ; h shifted by one step (64 rows)]
-// persistent blocks over (clip, 64-step) tiles; partial[block][256*128 + 256 (bias)]
+// G[n'][j] = sum_{b,t} da[b,t,n'] * z[b,j,t],  z = [x (64 rows) ; h shifted by one step (64 rows)]
+// persistent blocks over (clip, 64-step) tiles, next tile prefetched into registers during the MFMA phase;
+// partial[block][256*128 + 256 (bias)]
 __global__ __launch_bounds__(256) void lstm_wgrad_kernel(const float* __restrict__ da, const float* __restrict__ x,
                                                          const float* __restrict__ h, float* __restrict__ partial,
                                                          int B, int T) {
-    constexpr int NT = 64, ZS = NT + 1;
+    constexpr int NT = 64, ZS = 67;  // odd stride: the B operand is read down a column (32 lanes = 32 rows)
     extern __shared__ __align__(16) float smem[];
     float* ds = smem;                // [NT][256]
-    float* zs = smem + NT * 256;     // [128][ZS]
+    float* zs = smem + NT * 256;     // [128][ZS]; h rows are stored shifted: column tt holds h[t0 + tt - 1]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
     const int tilesPerClip = (T + NT - 1) / NT, ntiles = B * tilesPerClip;
     f32x16 acc[2][4];
@@ -321,29 +346,55 @@ __global__ __launch_bounds__(256) void lstm_wgrad_kernel(const float* __restrict
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
     float bsum = 0.f;
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    float4 sd[16], sx[4], sh[4];
+    float hh;
+    auto load_tile = [&](int tile) {               // branch-free (clamped addresses), masked when written to LDS
         const int b = tile / tilesPerClip, t0 = (tile % tilesPerClip) * NT;
-        __syncthreads();
-        const float* dab = da + ((size_t)b * T + t0) * 256;
-        for (int i = tid; i < NT * 64; i += 256) {
-            const int tt = i >> 6;
-            float4 v = reinterpret_cast<const float4*>(dab)[min(t0 + tt, T - 1) * 64 - t0 * 64 + (i & 63)];   // branch-free
-            if (t0 + tt >= T) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4* dab = reinterpret_cast<const float4*>(da + (size_t)b * T * 256);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int i = tid + k * 256;
+            sd[k] = dab[(size_t)min(t0 + (i >> 6), T - 1) * 64 + (i & 63)];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = tid + k * 256, j = i >> 4, q = i & 15;
+            const size_t off = ((size_t)b * 64 + j) * T + min(t0 + 4 * q, T - 4);
+            sx[k] = *reinterpret_cast<const float4*>(x + off);
+            sh[k] = *reinterpret_cast<const float4*>(h + off);
+        }
+        hh = h[((size_t)b * 64 + (tid & 63)) * T + max(t0 - 1, 0)];      // halo column h[t0 - 1]
+    };
+    auto write_tile = [&](int tile) {
+        const int t0 = (tile % tilesPerClip) * NT;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int i = tid + k * 256;
+            float4 v = sd[k];
+            if (t0 + (i >> 6) >= T) v = make_float4(0.f, 0.f, 0.f, 0.f);      // zero rows kill every product past T
             reinterpret_cast<float4*>(ds)[i] = v;
         }
-        for (int i = tid; i < 128 * NT; i += 256) {
-            const int j = i / NT, tt = i % NT, t = t0 + tt;
-            // rows 0..63: x[j][t];  rows 64..127: h[j-64][t-1] (zero initial state at t = 0); clamped address + select
-            const float* src = (j < 64) ? x + ((size_t)b * 64 + j) * T : h + ((size_t)b * 64 + (j - 64)) * T - 1;
-            const int tc = min(max(t, (j < 64) ? 0 : 1), T - 1);
-            float v = src[tc];
-            if (t >= T || (j >= 64 && t < 1)) v = 0.f;
-            zs[j * ZS + tt] = v;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = tid + k * 256, j = i >> 4, q = i & 15;
+            float* zx = zs + j * ZS + 4 * q;
+            zx[0] = sx[k].x; zx[1] = sx[k].y; zx[2] = sx[k].z; zx[3] = sx[k].w;
+            float* zh = zs + (64 + j) * ZS + 4 * q + 1;
+            zh[0] = sh[k].x; zh[1] = sh[k].y; zh[2] = sh[k].z; zh[3] = sh[k].w;
         }
-        __syncthreads();
-        // A[i = n][k = t] = ds[t][n] ; B[k = t][j] = zs[j][t]
-        const float* ap = ds + half * 256 + wave * 64 + l31;
-        const float* bp = zs + l31 * ZS + half;
+        if (tid < 64) zs[(64 + tid) * ZS] = (t0 >= 1) ? hh : 0.f;              // zero initial state
+    };
+    int tile = blockIdx.x;
+    if (tile < ntiles) load_tile(tile);
+    __syncthreads();
+    if (tile < ntiles) write_tile(tile);
+    __syncthreads();
+    // A[i = n'][k = t] = ds[t][n'] ; B[k = t][j] = zs[j][t]
+    const float* ap = ds + half * 256 + wave * 64 + l31;
+    const float* bp = zs + l31 * ZS + half;
+    while (tile < ntiles) {
+        const int next = tile + gridDim.x;
+        if (next < ntiles) load_tile(next);
 #pragma unroll 4
         for (int s = 0; s < NT / 2; ++s) {
             const float a0 = ap[2 * s * 256], a1 = ap[2 * s * 256 + 32];
@@ -354,7 +405,12 @@ __global__ __launch_bounds__(256) void lstm_wgrad_kernel(const float* __restrict
                 acc[1][nt] = mfma32(a1, bv, acc[1][nt]);
             }
         }
+#pragma unroll 8
         for (int tt = 0; tt < NT; ++tt) bsum += ds[tt * 256 + tid];
+        __syncthreads();
+        if (next < ntiles) write_tile(next);
+        __syncthreads();
+        tile = next;
     }
     float* out = partial + (size_t)blockIdx.x * (256 * 128 + 256);
 #pragma unroll
@@ -418,7 +474,8 @@ int wm_lstm_dx(const float* da, const float* w_ih, float* dx, int B, int T, hipS
     constexpr size_t lds = (size_t)(256 * 64 + 64 * 257) * sizeof(float);
     static bool done = false;
     if (!done) { WM_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_dx_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); done = true; }
-    hipLaunchKernelGGL(lstm_dx_kernel, dim3(B * ((T + 63) / 64)), dim3(256), lds, stream, da, w_ih, dx, T);
+    const int ntiles = B * ((T + 63) / 64);
+    hipLaunchKernelGGL(lstm_dx_kernel, dim3(ntiles < kNumCU ? ntiles : kNumCU), dim3(256), lds, stream, da, w_ih, dx, B, T);
     WM_CHECK_LAUNCH();
     return 0;
 }
@@ -426,7 +483,7 @@ int wm_lstm_dx(const float* da, const float* w_ih, float* dx, int B, int T, hipS
 // partial: >= 256 * (256*128 + 256) floats
 int wm_lstm_wgrad(const float* da, const float* x, const float* h, float* partial, float* dw_ih, float* dw_hh,
                   float* db_ih, float* db_hh, int B, int T, int accumulate, hipStream_t stream) {
-    constexpr size_t lds = (size_t)(64 * 256 + 128 * 65) * sizeof(float);
+    constexpr size_t lds = (size_t)(64 * 256 + 128 * 67) * sizeof(float);
     static bool done = false;
     if (!done) { WM_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); done = true; }
     const int ntiles = B * ((T + 63) / 64);

@@ -248,22 +248,57 @@ __global__ __launch_bounds__(256) void headN_bwd_kernel(const float* __restrict_
 #pragma unroll
     for (int r = 0; r < 16; ++r) { accw[0][r] = 0.f; accw[1][r] = 0.f; }
     float accb = 0.f;
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    // next tile is fetched into registers (16-B loads, clamped addresses, no branches) while this one is processed
+    constexpr int NG4 = (256 * NO + 3) / 4, NGV = (NG4 + 255) / 256;
+    float4 sx[16], sgv[NGV];
+    auto load_tile = [&](int tile) {
+        const int b = tile / tilesPerClip, t0 = (tile % tilesPerClip) * 256;
+        const float* xb = x + (size_t)b * 64 * T;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int i = tid + k * 256, c = i >> 6, q = i & 63;
+            sx[k] = *reinterpret_cast<const float4*>(xb + (size_t)c * T + min(t0 + 4 * q, T - 4));
+        }
+        // the g tile is 256*NO contiguous floats starting at a 16-B aligned address (t0 % 256 == 0, T % 4 == 0)
+        const float4* gb4 = reinterpret_cast<const float4*>(g + ((size_t)b * T + t0) * NO);
+        const int lim4 = ((T - t0 < 256 ? T - t0 : 256) * NO) / 4;            // whole float4s available in this clip
+#pragma unroll
+        for (int k = 0; k < NGV; ++k) sgv[k] = gb4[min(tid + k * 256, lim4 - 1)];
+    };
+    auto write_tile = [&](int tile) {
+        const int t0 = (tile % tilesPerClip) * 256;
+        const int nt = min(256, T - t0);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int i = tid + k * 256, c = i >> 6, q = i & 63;
+            float4 v = sx[k];
+            if (4 * q >= nt) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            float* d = xs + c * XS + 4 * q;
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        }
+#pragma unroll
+        for (int k = 0; k < NGV; ++k) {
+            const int f = tid + k * 256;
+            if (f < NG4) {
+                const float e[4] = {sgv[k].x, sgv[k].y, sgv[k].z, sgv[k].w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int i = 4 * f + j;
+                    if (i < 256 * NO) gsm[(i / NO) * GS + (i % NO)] = (i < nt * NO) ? e[j] : 0.f;
+                }
+            }
+        }
+    };
+    int tile = blockIdx.x;
+    if (tile < ntiles) load_tile(tile);
+    __syncthreads();                       // ws / gsm zero fill visible
+    if (tile < ntiles) write_tile(tile);
+    __syncthreads();
+    while (tile < ntiles) {
+        const int next = tile + gridDim.x;
+        if (next < ntiles) load_tile(next);
         const int b = tile / tilesPerClip, t0 = (tile % tilesPerClip) * 256;
         const int nt = min(256, T - t0);
-        __syncthreads();
-        const float* gb = g + ((size_t)b * T + t0) * NO;
-        for (int i = tid; i < 256 * NO; i += 256) {
-            const float gv = gb[min(i, nt * NO - 1)];                 // branch-free load, masked by the select
-            gsm[(i / NO) * GS + (i % NO)] = (i < nt * NO) ? gv : 0.f;
-        }
-        const float* xb = x + (size_t)b * 64 * T + t0;
-        for (int i = tid; i < 64 * 256; i += 256) {
-            const int c = i >> 8, tt = i & 255;
-            const float xv = xb[(size_t)c * T + min(tt, nt - 1)];
-            xs[c * XS + tt] = (tt < nt) ? xv : 0.f;
-        }
-        __syncthreads();
         // ---- dx tile: D[c][t]
         {
             f32x16 acc[2][2];
@@ -304,6 +339,10 @@ __global__ __launch_bounds__(256) void headN_bwd_kernel(const float* __restrict_
         }
         if (tid < NO)
             for (int tt = 0; tt < 256; ++tt) accb += gsm[tt * GS + tid];
+        __syncthreads();
+        if (next < ntiles) write_tile(next);
+        __syncthreads();
+        tile = next;
     }
     // fixed-order reduction of the four waves' dw tiles through LDS
     __syncthreads();
