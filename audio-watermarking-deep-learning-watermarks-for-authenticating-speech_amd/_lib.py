@@ -14,7 +14,7 @@ from typing import Dict, List, Tuple
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG_DIR)
 HEADER = os.path.join(_ROOT, "include", "wm_hip.h")
-LIB_PATH = os.path.join(_PKG_DIR, "libwm_hip.so")
+LIB_PATH = os.environ.get("WM_HIP_LIB", os.path.join(_PKG_DIR, "libwm_hip.so"))   # override: kernel experiments only
 
 _CT = {
     "int": ctypes.c_int, "float": ctypes.c_float, "double": ctypes.c_double, "long long": ctypes.c_longlong,

@@ -49,6 +49,50 @@ def _f32(*shape, device):
     return torch.empty(shape, dtype=torch.float32, device=device)
 
 
+# ---------------------------------------------------------------------------------------------- side stream
+# Weight-gradient GEMMs do not feed the data path of backward.  When the parameters carry a pre-allocated gradient
+# destination (optim.FlatAdam sets p._wm_grad = view of the flat gradient bucket and enables this), they are
+# launched on a second HIP stream and ACCUMULATE straight into that bucket (the Function then returns None for
+# them), so they overlap with the latency-bound LSTM recurrence and the HBM-bound element-wise kernels of the main
+# stream.  optim.FlatAdam.finish_backward() joins the streams before the all-reduce / update.
+_ASYNC = {"on": False, "side": None}
+
+
+def set_async_wgrad(on: bool):
+    _ASYNC["on"] = bool(on)
+
+
+def side_stream():
+    if _ASYNC["side"] is None:
+        _ASYNC["side"] = torch.cuda.Stream()
+    return _ASYNC["side"]
+
+
+def join_side_stream():
+    if _ASYNC["side"] is not None:
+        torch.cuda.current_stream().wait_stream(_ASYNC["side"])
+
+
+def _gdst(*params):
+    """gradient destinations registered on the parameters (None when the async path is off)"""
+    if not _ASYNC["on"]:
+        return tuple(None for _ in params)
+    return tuple(getattr(p, "_wm_grad", None) for p in params)
+
+
+def _on_side(inputs, fn):
+    """run fn() (kernel launches) on the side stream after everything enqueued so far on the current stream"""
+    main, side = torch.cuda.current_stream(), side_stream()
+    ev = torch.cuda.Event()
+    ev.record(main)
+    with torch.cuda.stream(side):
+        side.wait_event(ev)
+        for t in inputs:
+            if t is not None:
+                t.record_stream(side)
+        fn()
+
+
 def pack_w64(w: torch.Tensor, kw: int, mode: int) -> torch.Tensor:
     wp = _f32(kw * 4096, device=w.device)
     lib.wm_pack_w64(_p(w), _p(wp), kw, mode, _stream())
@@ -85,6 +129,7 @@ class ResBlockFn(torch.autograd.Function):
             mu1.copy_(rm1); is1.copy_(torch.rsqrt(rv1 + BN_EPS)); mu2.copy_(rm2); is2.copy_(torch.rsqrt(rv2 + BN_EPS))
         lib.wm_bn_add_relu(_p(x), _p(y2), _p(sc2), _p(sh2), _p(out), B, T, st)
         ctx.training = bool(training)
+        ctx.gdst = _gdst(w1, b1, w2, b2)
         ctx.save_for_backward(x, y1, y2, out, cst, w1, w2, g1, g2)
         return out
 
@@ -109,10 +154,18 @@ class ResBlockFn(torch.autograd.Function):
         stats = _f32(NCU * 128, device=dev)
         lib.wm_conv64(_p(dz2), _p(y2), _p(wp2d), _p(k2[0]), _p(k2[1]), _p(k2[2]), None, _p(y1), _p(sc1), _p(sh1), _p(dz1), _p(stats),
                       B, T, 3, 3, 1, st)
-        wpart = _f32(2 * NCU * (3 * 4096 + 64), device=dev)
-        dw2, db2 = torch.empty_like(w2), _f32(64, device=dev)
-        lib.wm_wgrad64(_p(dz2), _p(y2), _p(k2[0]), _p(k2[1]), _p(k2[2]), _p(y1), _p(sc1), _p(sh1), _p(wpart), _p(dw2), _p(db2),
-                       B, T, 3, 3, 1, 0, 0, st)
+        gw1, gb1, gw2, gb2 = ctx.gdst
+        side = all(g is not None for g in ctx.gdst)
+
+        def wgrad2():
+            wpart = _f32(2 * NCU * (3 * 4096 + 64), device=dev)
+            lib.wm_wgrad64(_p(dz2), _p(y2), _p(k2[0]), _p(k2[1]), _p(k2[2]), _p(y1), _p(sc1), _p(sh1), _p(wpart),
+                           _p(gw2 if side else dw2), _p(gb2 if side else db2), B, T, 3, 3, 1, 0, 1 if side else 0, _stream())
+        dw2, db2 = (None, None) if side else (torch.empty_like(w2), _f32(64, device=dev))
+        if side:
+            _on_side((dz2, y2, k2, y1, cst), wgrad2)
+        else:
+            wgrad2()
         k1 = _f32(3, 64, device=dev)
         dg1, dbe1 = _f32(64, device=dev), _f32(64, device=dev)
         lib.wm_bn_bwd_finalize(_p(stats), NCU, n, _p(g1), _p(mu1), _p(is1), _p(k1[0]), _p(k1[1]), _p(k1[2]), _p(dg1), _p(dbe1), 0, ev, st)
@@ -120,9 +173,15 @@ class ResBlockFn(torch.autograd.Function):
         wp1d = pack_w64(w1, 3, 1)
         dx = torch.empty_like(x)
         lib.wm_conv64(_p(dz1), _p(y1), _p(wp1d), _p(k1[0]), _p(k1[1]), _p(k1[2]), None, _p(dz2), None, None, _p(dx), None, B, T, 3, 3, 2, st)
-        dw1, db1 = torch.empty_like(w1), _f32(64, device=dev)
-        lib.wm_wgrad64(_p(dz1), _p(y1), _p(k1[0]), _p(k1[1]), _p(k1[2]), _p(x), None, None, _p(wpart), _p(dw1), _p(db1),
-                       B, T, 3, 3, 0, 0, 0, st)
+        def wgrad1():
+            wpart = _f32(2 * NCU * (3 * 4096 + 64), device=dev)
+            lib.wm_wgrad64(_p(dz1), _p(y1), _p(k1[0]), _p(k1[1]), _p(k1[2]), _p(x), None, None, _p(wpart),
+                           _p(gw1 if side else dw1), _p(gb1 if side else db1), B, T, 3, 3, 0, 0, 1 if side else 0, _stream())
+        dw1, db1 = (None, None) if side else (torch.empty_like(w1), _f32(64, device=dev))
+        if side:
+            _on_side((dz1, y1, k1, x), wgrad1)
+        else:
+            wgrad1()
         return dx, dw1, db1, dg1, dbe1, dw2, db2, dg2, dbe2, None, None, None, None, None, None, None
 
 
@@ -221,6 +280,7 @@ class LSTMFn(torch.autograd.Function):
         if need_grad:
             gates, cst = xp, _f32(B, T, 64, device=dev)     # activations overwrite the projections in place
             lib.wm_lstm_fwd(_p(xp), _p(w_hh), _p(h), _p(gates), _p(cst), B, T, st)
+            ctx.gdst = _gdst(w_ih, w_hh, b_ih, b_hh)
             ctx.save_for_backward(x, h, gates, cst, w_ih, w_hh)
         else:
             lib.wm_lstm_fwd(_p(xp), _p(w_hh), _p(h), None, None, B, T, st)
@@ -235,6 +295,15 @@ class LSTMFn(torch.autograd.Function):
         lib.wm_lstm_bwd(_p(gates), _p(cst), _p(dh), _p(w_hh), B, T, st)          # gates now holds da
         dx = torch.empty_like(x)
         lib.wm_lstm_dx(_p(gates), _p(w_ih), _p(dx), B, T, st)
+        side = all(g is not None for g in ctx.gdst)
+        if side:
+            gwi, gwh, gbi, gbh = ctx.gdst
+
+            def wg():
+                part = _f32(NCU * (256 * 128 + 256), device=dev)
+                lib.wm_lstm_wgrad(_p(gates), _p(x), _p(h), _p(part), _p(gwi), _p(gwh), _p(gbi), _p(gbh), B, T, 1, _stream())
+            _on_side((gates, x, h), wg)
+            return dx, None, None, None, None
         part = _f32(NCU * (256 * 128 + 256), device=dev)
         dwi, dwh = torch.empty_like(w_ih), torch.empty_like(w_hh)
         dbi, dbh = _f32(256, device=dev), _f32(256, device=dev)
@@ -278,6 +347,7 @@ class ConvT7Fn(torch.autograd.Function):
         pro = 2 if vec is not None else 0
         lib.wm_conv64(_p(x), None, _p(wp), _p(vec), None, None, _p(b), None, None, None, _p(y), None, B, T, 7, pro, 0, _stream())
         ctx.has_vec = vec is not None
+        ctx.gdst = _gdst(w, b)
         ctx.save_for_backward(x, w, vec if vec is not None else x.new_empty(0))
         return y
 
@@ -291,10 +361,18 @@ class ConvT7Fn(torch.autograd.Function):
         wpd = pack_w64(w, 7, 3)
         dx = torch.empty_like(x)
         lib.wm_conv64(_p(g), None, _p(wpd), None, None, None, None, None, None, None, _p(dx), None, B, T, 7, 0, 3, st)
-        part = _f32(2 * NCU * (7 * 4096 + 64), device=dev)
-        dw, db = torch.empty_like(w), _f32(64, device=dev)
-        lib.wm_wgrad64(_p(g), None, None, None, None, _p(x), _p(vec), None, _p(part), _p(dw), _p(db), B, T, 7, 0,
-                       2 if vec is not None else 0, 1, 0, st)
+        gw, gbias = ctx.gdst
+        side = gw is not None and gbias is not None
+
+        def wg():
+            part = _f32(2 * NCU * (7 * 4096 + 64), device=dev)
+            lib.wm_wgrad64(_p(g), None, None, None, None, _p(x), _p(vec), None, _p(part), _p(gw if side else dw),
+                           _p(gbias if side else db), B, T, 7, 0, 2 if vec is not None else 0, 1, 1 if side else 0, _stream())
+        dw, db = (None, None) if side else (torch.empty_like(w), _f32(64, device=dev))
+        if side:
+            _on_side((g, x, vec), wg)
+        else:
+            wg()
         dvec = None
         if vec is not None and ctx.needs_input_grad[1]:
             dvec = _f32(B, 64, device=dev)

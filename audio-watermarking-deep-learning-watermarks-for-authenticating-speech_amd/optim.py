@@ -10,11 +10,12 @@ from __future__ import annotations
 
 import torch
 
+from . import ops
 from ._lib import lib
 
 
 class FlatAdam:
-    def __init__(self, modules, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+    def __init__(self, modules, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, overlap_wgrad=False):
         self.params = [p for m in modules for p in m.parameters()]
         if not self.params:
             raise ValueError("no parameters")
@@ -32,14 +33,21 @@ class FlatAdam:
             self.flat[off:off + k].copy_(p.data.reshape(-1))
             p.data = self.flat[off:off + k].view_as(p)
             p.grad = self.grad[off:off + k].view_as(p)
+            p._wm_grad = p.grad if overlap_wgrad else None     # destination for the side-stream weight-gradient GEMMs
             off += k
+        ops.set_async_wgrad(overlap_wgrad)
         self.lr, self.betas, self.eps = float(lr), (float(betas[0]), float(betas[1])), float(eps)
         self.t = 0
 
     def zero_grad(self, set_to_none=False):
         self.grad.zero_()          # the views stay attached; autograd accumulates into them in place
 
+    def finish_backward(self):
+        """join the weight-gradient side stream (call after backward, before reading / all-reducing self.grad)"""
+        ops.join_side_stream()
+
     def step(self):
+        self.finish_backward()
         self.t += 1
         lib.wm_adam_step(self.flat.data_ptr(), self.grad.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), self.flat.numel(),
                          self.lr, self.betas[0], self.betas[1], self.eps, self.t, torch.cuda.current_stream().cuda_stream)

@@ -40,6 +40,8 @@ def train_step(generator, detector, optimizer, s, message, grad_sync=None):
     optimizer.zero_grad(set_to_none=not hasattr(optimizer, "flat"))
     total, out = forward_losses(generator, detector, s, message)
     total.backward()
+    if hasattr(optimizer, "finish_backward"):
+        optimizer.finish_backward()
     if grad_sync is not None:
         grad_sync()
     optimizer.step()
