@@ -176,11 +176,21 @@ def main():
         clips_per_launch = timer.mean_clips() if k_ms else 0.0
         flops_launch = 2.0 * 64 * 64 * 3 * T * clips_per_launch
         bytes_launch = 2.0 * 64 * T * 4 * clips_per_launch
+        # HBM traffic of the dominant kernel from the committed PMC pass (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
+        # separate runs, gfx950 FETCH x2 correction; profiles/r01_pmc_fetch_write_b256.json) -- same B=256 workload only
+        traffic = None
+        try:
+            if args.batch == 256:
+                pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_fetch_write_b256.json")))["kernels"]
+                ks = [v["hbm_bytes_per_launch_corrected"] for k, v in pm.items() if k.startswith("conv64_kernel<3, 256")]
+                traffic = sum(ks) / len(ks) if ks else None
+        except Exception:
+            traffic = None
         roofline = None
         if k_ms:
             ach = flops_launch / (k_ms * 1e-3) / 1e12
             roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                        "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
                         "kernel": "conv64_kernel<KW=3> forward (wm_conv64: Conv1d(64,64,3)+bias, BN+ReLU fused on load, BN sums in epilogue)",
                         "avg_launch_ms": round(k_ms, 4), "launches_timed": len(timer.events),
                         "algorithmic_flops_per_launch": flops_launch, "algorithmic_bytes_per_launch": bytes_launch,

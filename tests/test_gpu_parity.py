@@ -480,3 +480,45 @@ def test_flat_adam_and_side_stream_wgrad(awm, dev):
             # Adam's first steps move every weight by ~lr regardless of gradient scale: compare on that scale
             assert float((sd1[k] - sd2[k]).abs().max()) <= 2e-4, k
     assert list(G2.state_dict().keys()) == list(gsd.keys())
+
+
+def test_file_level_embed_detect_batched(awm, dev):
+    """N1: one batched call over all 1-s segments == the reference's per-segment B=1 loop (py/main16.py:996-1026,
+    :1133-1164), incl. the zero-padded remainder segment and per-segment messages."""
+    G, D, gsd, dsd = make_models(awm, dev)
+    n = 2 * 16000 + 5000
+    w = O.synthetic_clips(1, seed=97, T=48000).reshape(1, -1)[:, :n]
+    msgs = torch.tensor([11, 22222, 65535])
+    wm, delta, orig = awm.embed_waveform(w, G, device=dev, messages=msgs)
+    assert wm.shape == (1, n) and delta.shape == (1, n) and torch.equal(orig, w)
+    ref_delta = []
+    with torch.no_grad():
+        for i in range(3):
+            seg = w[:, i * 16000:(i + 1) * 16000]
+            seg = torch.nn.functional.pad(seg, (0, 16000 - seg.shape[1])).unsqueeze(0)
+            ref_delta.append(O.generator_forward(gsd, seg, msgs[i:i + 1]).squeeze(0))
+    ref_delta = torch.cat(ref_delta, dim=1)[:, :n]
+    check(delta, ref_delta, FWD_TOL, "file-level delta")
+    check(wm, w + ref_delta, FWD_TOL, "file-level watermarked")
+    res = awm.generate_watermarked_audio(w, G, device=dev)
+    assert set(res) == {"watermarked_waveform", "delta_waveform", "original_waveform", "metrics"}
+    assert set(res["metrics"]) == {"watermark_rms", "si_snr_db", "power_ratio_db"}
+    det = awm.detect_waveform(wm, D, device=dev)
+    with torch.no_grad():
+        probs, mls = [], []
+        for i in range(3):
+            seg = wm[:, i * 16000:(i + 1) * 16000]
+            valid = seg.shape[1]
+            lg = O.detector_forward(dsd, torch.nn.functional.pad(seg, (0, 16000 - valid)).unsqueeze(0))
+            probs.append(torch.sigmoid(lg[:, :valid, 0]))
+            mls.append(lg[:, :valid, 1:].mean(dim=1))
+        ref_probs = torch.cat(probs, dim=1).flatten()
+        ref_ml = torch.cat(mls).mean(dim=0)
+    assert det["temporal_probs"].shape == (n,)
+    check(torch.from_numpy(det["temporal_probs"]), ref_probs, FWD_TOL, "temporal probs")
+    assert abs(det["mean_probability"] - float(ref_probs.mean())) < 1e-5
+    assert det["decision"] in ("WATERMARKED", "NOT WATERMARKED") and det["is_watermarked"] == (det["mean_probability"] > 0.5)
+    check(torch.tensor(det["message_confidence"]), torch.sigmoid(ref_ml), FWD_TOL, "message confidence")
+    assert det["predicted_message"] == (ref_ml > 0).int().tolist()
+    ev = awm.evaluate_batches(G, D, [O.synthetic_clips(4, seed=98)], device=dev)
+    assert set(ev) == {"watermarked_prob", "clean_prob", "bit_accuracy", "delta_rms"} and all(np.isfinite(v) for v in ev.values())
