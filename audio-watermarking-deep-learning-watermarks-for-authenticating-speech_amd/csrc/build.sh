@@ -6,7 +6,7 @@ HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result"
 mkdir -p obj
 pids=()
-for f in conv64 bn small_convs lstm postproc stft_loss losses; do
+for f in conv64 bn small_convs lstm postproc stft_loss losses gconv; do
   if [ ! -f obj/$f.o ] || [ $f.hip -nt obj/$f.o ] || [ wm_common.hpp -nt obj/$f.o ]; then
     $HIPCC $FLAGS -c $f.hip -o obj/$f.o &
     pids+=($!)

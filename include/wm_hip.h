@@ -115,6 +115,21 @@ int wm_l1_bwd(const float* x, const float* g, float* dx, long long n, wm_stream_
 int wm_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,
                  int step, wm_stream_t stream);
 
+/* ---- main14b_2 deep-residual variant (py/main14b_2.py:83-224, BASELINE config 5): generic-shape convolutions -------
+ * y[nb][co][t'] = act(bias[co] + vec[nb][co] + res[..] + sum_{ci,k} wp[ci*K+k][m] * x[nb][ci][n*S + k - P])
+ *   st == 1: m = co, t' = n  (strided Conv1d :87-92, nn.Linear :134, Conv1d k7 :121,:139,:153)
+ *   st  > 1: m = co*st + phase, t' = n*st + phase - shp  (ConvTranspose1d(k=2*st, stride st, padding st/2) :147 as a
+ *            2-tap convolution + pixel shuffle).  act: 0 none | 1 ELU (:90).  wp is packed by the host mirror.        */
+int wm_gconv(const float* x, const float* wp, const float* bias, const float* vec, const float* res, float* y, int NB,
+             int Cin, int Lin, int K, int S, int P, int Mtot, int Nout, int st, int shp, int Cout, int Lout, int act,
+             wm_stream_t stream);
+/* [A][C][L] -> [L][C][A]: batch-major <-> time-major sequence layout around nn.LSTM (:137) */
+int wm_permute_acl(const float* x, float* y, int A, int C, int L, wm_stream_t stream);
+/* one time step of nn.LSTM(hd, hd, num_layers=2) (:137) for one layer: gate GEMM on the matrix cores + cell update;
+ * tensors are [rows][Bn] (batch contiguous), whhT = W_hh^T [hd][4hd], hprev/cprev NULL = zero initial state          */
+int wm_lstm_h_step_fwd(const float* xp, const float* whhT, const float* hprev, const float* cprev, float* hout, float* cout,
+                       float* gates_out, int H, int Bn, wm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,91 @@
+"""GPU parity of the main14b_2 variant (BASELINE config 5), forward path: generic conv kernel vs torch CPU ops on
+awkward shapes, whole Generator / Detector vs the reference fixtures (tests/golden/main14b2_golden.npz) and the oracle."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import wm_oracle as O
+from oracle import wm_oracle_14b2 as O2
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def M():
+    import awm_amd
+    awm_amd.lib.load()
+    from awm_amd import main14b_2
+    return main14b_2
+
+
+@pytest.fixture(scope="module")
+def g2():
+    import os
+    return np.load(os.path.join(os.path.dirname(__file__), "golden", "main14b2_golden.npz"))
+
+
+def rel(a, ref):
+    a, ref = a.detach().double().cpu(), ref.detach().double().cpu()
+    assert a.shape == ref.shape, (a.shape, ref.shape)
+    return float((a - ref).abs().max() / (ref.abs().max() + 1e-30))
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale
+
+
+@pytest.mark.parametrize("cin,cout,k,stride,pad,L", [(1, 32, 7, 1, 3, 1000), (32, 64, 3, 2, 1, 1000), (64, 128, 3, 4, 1, 501),
+                                                     (128, 256, 3, 5, 1, 400), (256, 512, 3, 8, 1, 399), (32, 64, 1, 2, 0, 1000),
+                                                     (8, 1, 7, 1, 3, 700), (32, 17, 7, 1, 3, 333), (512, 256, 1, 1, 0, 50)])
+def test_gconv_matches_conv1d(M, cin, cout, k, stride, pad, L):
+    dev = torch.device("cuda:0")
+    x, w, b = rnd(2, cin, L, seed=1), rnd(cout, cin, k, seed=2, scale=0.1), rnd(cout, seed=3)
+    ref = F.elu(F.conv1d(x, w, b, stride=stride, padding=pad))
+    with torch.no_grad():
+        y = M._gconv(x.to(dev), w.to(dev), b.to(dev), stride, pad, act=1)
+    assert rel(y, ref) <= TOL
+    res = rnd(*ref.shape, seed=4)
+    ref2 = F.conv1d(x, w, b, stride=stride, padding=pad) + res
+    with torch.no_grad():
+        y2 = M._gconv(x.to(dev), w.to(dev), b.to(dev), stride, pad, act=0, res=res.to(dev))
+    assert rel(y2, ref2) <= TOL
+
+
+@pytest.mark.parametrize("cin,cout,st,L", [(128, 64, 8, 50), (64, 32, 5, 400), (32, 16, 4, 2001), (16, 8, 2, 1000), (512, 256, 8, 50)])
+def test_gconvT_matches_conv_transpose1d(M, cin, cout, st, L):
+    dev = torch.device("cuda:0")
+    x, w, b = rnd(2, cin, L, seed=5), rnd(cin, cout, 2 * st, seed=6, scale=0.1), rnd(cout, seed=7)
+    ref = F.conv_transpose1d(x, w, b, stride=st, padding=st // 2)
+    with torch.no_grad():
+        y = M._gconvT(x.to(dev), w.to(dev), b.to(dev), st)
+    assert rel(y, ref) <= TOL
+
+
+@pytest.mark.parametrize("hd", [256, 32])
+def test_main14b2_forward_golden(M, g2, hd):
+    dev = torch.device("cuda:0")
+    torch.manual_seed(42)
+    G, D = M.Generator(hidden_dim=hd), M.Detector()
+    gsd = {k: v.detach().clone() for k, v in G.state_dict().items()}
+    dsd = {k: v.detach().clone() for k, v in D.state_dict().items()}
+    G.to(dev).eval(); D.to(dev).eval()
+    s = O.synthetic_clips(2, seed=1234)
+    msg = torch.from_numpy(g2["message"])
+    with torch.no_grad():
+        d = G(s.to(dev), msg.to(dev))
+        assert d.shape == (2, 1, 16000)
+        assert rel(d, torch.from_numpy(g2[f"hd{hd}_delta"])) <= TOL
+        d0 = G(s.to(dev))
+        assert rel(d0[..., ::97], torch.from_numpy(g2[f"hd{hd}_delta_nomsg_sub"])) <= TOL
+        lg = D(s.to(dev) + d)
+        assert lg.shape == (2, 17, 16000)
+        assert rel(lg[..., ::97], torch.from_numpy(g2[f"hd{hd}_logits_sub"])) <= TOL
+        # a different batch / length against the oracle directly
+        s3 = O.synthetic_clips(3, seed=77, T=8000)
+        m3 = torch.tensor([1, 2, 65535])
+        assert rel(G(s3.to(dev), m3.to(dev)), O2.generator_forward(gsd, s3, m3)) <= TOL
+        assert rel(D(s3.to(dev)), O2.detector_forward(dsd, s3)) <= TOL
+    with pytest.raises(NotImplementedError):
+        G(s.to(dev), msg.to(dev))          # autograd recording is refused: backward of this variant is not built
