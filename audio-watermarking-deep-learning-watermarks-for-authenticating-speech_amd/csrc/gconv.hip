@@ -100,10 +100,10 @@ __global__ void permute_acl_kernel(const float* __restrict__ x, float* __restric
 //   gates[q*H + u][b] = xp[q*H + u][b] + sum_k whhT[k][q*H + u] * hprev[k][b]          (MFMA, K = H)
 //   c = sig(f) c + sig(i) tanh(g);  h = sig(o) tanh(c)
 // wave = 32 units x 32 batch columns x 4 gates.  hprev == nullptr means zero initial state.
-__global__ __launch_bounds__(64) void lstm_h_step_fwd_kernel(const float* __restrict__ xp, const float* __restrict__ whhT,
+__global__ __launch_bounds__(64) void lstm_h_step_fwd_kernel(const float* xp, const float* __restrict__ whhT,
                                                             const float* __restrict__ hprev, const float* __restrict__ cprev,
                                                             float* __restrict__ hout, float* __restrict__ cout,
-                                                            float* __restrict__ gates_out, int H, int Bn) {
+                                                            float* gates_out /* may alias xp */, int H, int Bn) {
     const int lane = threadIdx.x, half = lane >> 5, l31 = lane & 31;
     const int u0 = blockIdx.x * 32, b0 = blockIdx.y * 32;
     const int bcol = min(b0 + l31, Bn - 1);
@@ -143,6 +143,139 @@ __global__ __launch_bounds__(64) void lstm_h_step_fwd_kernel(const float* __rest
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Generic weight gradient:  G[a][b][k] += sum_{nb,t} A[nb][a][t] * Bx[nb][b][t*S + k - P]      (k < K <= 16)
+//   Conv1d:           A = dL/dy (rows = out channels),  Bx = layer input  -> dW[out][in][k]
+//   ConvTranspose1d:  A = layer input (rows = in channels), Bx = dL/dy    -> dW[in][out][k]   (S = stride, P = padding)
+//   Linear / LSTM:    K = 1.
+// One wave owns a 32x32 (a,b) tile for every tap (K accumulators); the workgroup's 4 waves split each 64-position
+// chunk; a workgroup walks a strided list of (nb, chunk) pairs and flushes once with float atomics (the slabs of the
+// largest layer would be 8 MB per workgroup, so the fixed-order slab reduce of the main16 kernels does not scale here;
+// consequence: the summation order over workgroups is not fixed, results are reproducible to fp32 round-off only).
+// dbias[a] += sum A[a][t] is produced by the b-tile-0 workgroups.
+template <int KMAX>
+__global__ __launch_bounds__(256) void gwgrad_kernel(const float* __restrict__ A, const float* __restrict__ Bx,
+                                                     float* __restrict__ G, float* __restrict__ dbias, int NB, int Ca, int Cb,
+                                                     int La, int Lb, int K, int S, int P) {
+    constexpr int TC = 64;
+    extern __shared__ __align__(16) float smem[];
+    const int BW = (TC - 1) * S + K;            // Bx span of a chunk
+    const int AS = TC + 1, BS = BW | 1;         // odd strides: operands are read down a column
+    float* As = smem;                           // [32][AS]
+    float* Bs = smem + 32 * AS;                 // [32][BS]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const int a0 = blockIdx.x * 32, b0 = blockIdx.y * 32;
+    const int nchunks = (La + TC - 1) / TC, nwork = NB * nchunks;
+    f32x16 acc[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
+    float bsum = 0.f;
+    for (int w = blockIdx.z; w < nwork; w += gridDim.z) {
+        const int nb = w / nchunks, t0 = (w - nb * nchunks) * TC;
+        const float* Ab = A + (size_t)nb * Ca * La;
+        const float* Bb = Bx + (size_t)nb * Cb * Lb;
+        __syncthreads();
+        for (int i = tid; i < 32 * TC; i += 256) {
+            const int r = i / TC, j = i - r * TC, a = a0 + r, t = t0 + j;
+            const float v = Ab[(size_t)min(a, Ca - 1) * La + min(t, La - 1)];
+            const float vv = (a < Ca && t < La) ? v : 0.f;
+            As[r * AS + j] = vv;
+        }
+        const int u0 = t0 * S - P;
+        for (int i = tid; i < 32 * BW; i += 256) {
+            const int r = i / BW, j = i - r * BW, b = b0 + r, u = u0 + j;
+            const float v = Bb[(size_t)min(b, Cb - 1) * Lb + min(max(u, 0), Lb - 1)];
+            Bs[r * BS + j] = (b < Cb && u >= 0 && u < Lb) ? v : 0.f;
+        }
+        __syncthreads();
+        // wave `wave` takes positions [16*wave, 16*wave+16) of the chunk: 8 k-steps of 2 positions
+        const float* ap = As + l31 * AS + 16 * wave + half;
+        const float* bp = Bs + l31 * BS + (16 * wave + half) * S;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const float av = ap[2 * s];
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k)
+                if (k < K) acc[k] = mfma32(av, bp[2 * s * S + k], acc[k]);
+        }
+        if (dbias && blockIdx.y == 0 && tid < 32)
+            for (int j = 0; j < TC; ++j) bsum += As[tid * AS + j];
+    }
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        if (k < K) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int a = a0 + mfma_row(r, half), b = b0 + l31;
+                if (a < Ca && b < Cb) atomicAdd(G + ((size_t)a * Cb + b) * K + k, acc[k][r]);
+            }
+        }
+    }
+    if (dbias && blockIdx.y == 0 && tid < 32 && a0 + tid < Ca) atomicAdd(dbias + a0 + tid, bsum);
+}
+
+// dz = g * elu'(y) with y = ELU(z):  elu'(z) = 1 for y > 0 else y + 1   (alpha = 1)
+__global__ void elu_bwd_kernel(const float* __restrict__ g, const float* __restrict__ y, float* __restrict__ dz, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float yy = y[i];
+    dz[i] = g[i] * (yy > 0.f ? 1.f : yy + 1.f);
+}
+
+// backward of one LSTM time step (pointwise part): gates (activated i,f,g,o) -> pre-activation gradients, in place
+//   dh = total gradient w.r.t. h_t, dc (in/out) = gradient w.r.t. c_t coming from step t+1 -> w.r.t. c_{t-1}
+__global__ void lstm_h_step_bwd_kernel(float* __restrict__ gates, const float* __restrict__ c, const float* __restrict__ cprev,
+                                       const float* __restrict__ dh, float* __restrict__ dc, int H, int Bn) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= H * Bn) return;
+    const size_t hb = (size_t)H * Bn;
+    const float gi = gates[i], gf = gates[hb + i], gg = gates[2 * hb + i], go = gates[3 * hb + i];
+    const float tc = tanhf(c[i]);
+    const float dht = dh[i];
+    const float dct = dc[i] + dht * go * (1.f - tc * tc);
+    const float cp = cprev ? cprev[i] : 0.f;
+    gates[i] = dct * gg * gi * (1.f - gi);
+    gates[hb + i] = dct * cp * gf * (1.f - gf);
+    gates[2 * hb + i] = dct * gi * (1.f - gg * gg);
+    gates[3 * hb + i] = dht * tc * go * (1.f - go);
+    dc[i] = dct * gf;
+}
+
+// out[c] += sum_{nb,t} x[nb][c][t]      (bias gradient of the transposed convolutions); one block per channel
+__global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restrict__ x, float* __restrict__ out, int NB, int C, int L) {
+    __shared__ float scratch[4];
+    const int c = blockIdx.x;
+    float s = 0.f;
+    for (int nb = 0; nb < NB; ++nb) {
+        const float* r = x + ((size_t)nb * C + c) * L;
+        for (int t = threadIdx.x; t < L; t += 256) s += r[t];
+    }
+    s = block_sum<4>(s, scratch);
+    if (threadIdx.x == 0) out[c] += s;
+}
+
+// out[row] = sum_t x[row][t] for any row length
+__global__ __launch_bounds__(256) void rowsum_any_kernel(const float* __restrict__ x, float* __restrict__ out, int L) {
+    __shared__ float scratch[4];
+    const float* r = x + (size_t)blockIdx.x * L;
+    float s = 0.f;
+    for (int t = threadIdx.x; t < L; t += 256) s += r[t];
+    s = block_sum<4>(s, scratch);
+    if (threadIdx.x == 0) out[blockIdx.x] = s;
+}
+
+// dtable[idx[b]][:] += dvec[b][:]   (dense embedding gradient for any embedding width)
+__global__ void rows_scatter_add_kernel(float* __restrict__ dtable, const long long* __restrict__ idx,
+                                        const float* __restrict__ dvec, int Bn, int dim, int nrows) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Bn * dim) return;
+    const long long m = idx[i / dim];
+    if (m < 0 || m >= nrows) return;
+    atomicAdd(dtable + (size_t)m * dim + (i % dim), dvec[i]);
+}
+
 }  // namespace
 
 extern "C" {
@@ -164,6 +297,63 @@ int wm_gconv(const float* x, const float* wp, const float* bias, const float* ve
 int wm_permute_acl(const float* x, float* y, int A, int C, int L, hipStream_t stream) {
     const size_t n = (size_t)A * C * L;
     hipLaunchKernelGGL(permute_acl_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, x, y, A, C, L);
+    WM_CHECK_LAUNCH();
+    return 0;
+}
+
+// G[a][b][k] += sum_{nb,t} A[nb][a][t] * Bx[nb][b][t*S + k - P]; dbias[a] += sum A (dbias may be NULL).  ACCUMULATES
+// (float atomics): the caller zeroes G / dbias.  K <= 16.
+int wm_gwgrad(const float* A, const float* Bx, float* G, float* dbias, int NB, int Ca, int Cb, int La, int Lb, int K, int S,
+              int P, hipStream_t stream) {
+    if (NB <= 0 || Ca <= 0 || Cb <= 0 || La <= 0 || K <= 0 || K > 16 || S <= 0 || S > 8) return (int)hipErrorInvalidValue;
+    const int nchunks = (La + 63) / 64, nwork = NB * nchunks;
+    const int tiles = ((Ca + 31) / 32) * ((Cb + 31) / 32);
+    int gz = (2048 + tiles - 1) / tiles;          // ~2048 workgroups in flight overall
+    if (gz > nwork) gz = nwork;
+    if (gz < 1) gz = 1;
+    const size_t lds = (size_t)(32 * 65 + 32 * ((63 * S + K) | 1)) * sizeof(float);
+    dim3 grid((Ca + 31) / 32, (Cb + 31) / 32, gz);
+    static bool done = false;
+    if (!done) {
+        WM_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gwgrad_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        WM_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gwgrad_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        WM_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gwgrad_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        done = true;
+    }
+    if (K <= 4) hipLaunchKernelGGL(gwgrad_kernel<4>, grid, dim3(256), lds, stream, A, Bx, G, dbias, NB, Ca, Cb, La, Lb, K, S, P);
+    else if (K <= 8) hipLaunchKernelGGL(gwgrad_kernel<8>, grid, dim3(256), lds, stream, A, Bx, G, dbias, NB, Ca, Cb, La, Lb, K, S, P);
+    else hipLaunchKernelGGL(gwgrad_kernel<16>, grid, dim3(256), lds, stream, A, Bx, G, dbias, NB, Ca, Cb, La, Lb, K, S, P);
+    WM_CHECK_LAUNCH();
+    return 0;
+}
+
+int wm_elu_bwd(const float* g, const float* y, float* dz, long long n, hipStream_t stream) {
+    hipLaunchKernelGGL(elu_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, g, y, dz, (size_t)n);
+    WM_CHECK_LAUNCH();
+    return 0;
+}
+
+int wm_lstm_h_step_bwd(float* gates, const float* c, const float* cprev, const float* dh, float* dc, int H, int Bn,
+                       hipStream_t stream) {
+    hipLaunchKernelGGL(lstm_h_step_bwd_kernel, dim3((H * Bn + 255) / 256), dim3(256), 0, stream, gates, c, cprev, dh, dc, H, Bn);
+    WM_CHECK_LAUNCH();
+    return 0;
+}
+
+int wm_channel_sum(const float* x, float* out, int NB, int C, int L, hipStream_t stream) {
+    hipLaunchKernelGGL(channel_sum_kernel, dim3(C), dim3(256), 0, stream, x, out, NB, C, L);
+    WM_CHECK_LAUNCH();
+    return 0;
+}
+
+int wm_rowsum_any(const float* x, float* out, int rows, int L, hipStream_t stream) {
+    hipLaunchKernelGGL(rowsum_any_kernel, dim3(rows), dim3(256), 0, stream, x, out, L);
+    WM_CHECK_LAUNCH();
+    return 0;
+}
+
+int wm_rows_scatter_add(float* dtable, const long long* idx, const float* dvec, int Bn, int dim, int nrows, hipStream_t stream) {
+    hipLaunchKernelGGL(rows_scatter_add_kernel, dim3((Bn * dim + 255) / 256), dim3(256), 0, stream, dtable, idx, dvec, Bn, dim, nrows);
     WM_CHECK_LAUNCH();
     return 0;
 }

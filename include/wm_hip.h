@@ -123,6 +123,21 @@ int wm_adam_step(float* p, const float* g, float* m, float* v, long long n, floa
 int wm_gconv(const float* x, const float* wp, const float* bias, const float* vec, const float* res, float* y, int NB,
              int Cin, int Lin, int K, int S, int P, int Mtot, int Nout, int st, int shp, int Cout, int Lout, int act,
              wm_stream_t stream);
+/* generic weight gradient (ACCUMULATES with float atomics; caller zeroes G/dbias):
+ *   G[a][b][k] += sum_{nb,t} A[nb][a][t] * Bx[nb][b][t*S + k - P],  dbias[a] += sum A   (Conv1d: A = dL/dy, Bx = input;
+ *   ConvTranspose1d: A = input, Bx = dL/dy; Linear / LSTM: K = 1)                                                      */
+int wm_gwgrad(const float* A, const float* Bx, float* G, float* dbias, int NB, int Ca, int Cb, int La, int Lb, int K, int S,
+              int P, wm_stream_t stream);
+/* dz = g * ELU'(z) from y = ELU(z) (py/main14b_2.py:90,:96,:101) */
+int wm_elu_bwd(const float* g, const float* y, float* dz, long long n, wm_stream_t stream);
+/* pointwise backward of one LSTM step: gates (activations) -> pre-activation gradients in place; dc in/out */
+int wm_lstm_h_step_bwd(float* gates, const float* c, const float* cprev, const float* dh, float* dc, int H, int Bn,
+                       wm_stream_t stream);
+/* out[c] += sum_{nb,t} x[nb][c][t] (ACCUMULATES) ; out[row] = sum_t x[row][t] for any row length */
+int wm_channel_sum(const float* x, float* out, int NB, int C, int L, wm_stream_t stream);
+int wm_rowsum_any(const float* x, float* out, int rows, int L, wm_stream_t stream);
+/* dense embedding gradient for any width: dtable[idx[b]][:] += dvec[b][:] */
+int wm_rows_scatter_add(float* dtable, const long long* idx, const float* dvec, int Bn, int dim, int nrows, wm_stream_t stream);
 /* [A][C][L] -> [L][C][A]: batch-major <-> time-major sequence layout around nn.LSTM (:137) */
 int wm_permute_acl(const float* x, float* y, int A, int C, int L, wm_stream_t stream);
 /* one time step of nn.LSTM(hd, hd, num_layers=2) (:137) for one layer: gate GEMM on the matrix cores + cell update;

@@ -87,5 +87,40 @@ def test_main14b2_forward_golden(M, g2, hd):
         m3 = torch.tensor([1, 2, 65535])
         assert rel(G(s3.to(dev), m3.to(dev)), O2.generator_forward(gsd, s3, m3)) <= TOL
         assert rel(D(s3.to(dev)), O2.detector_forward(dsd, s3)) <= TOL
-    with pytest.raises(NotImplementedError):
-        G(s.to(dev), msg.to(dev))          # autograd recording is refused: backward of this variant is not built
+
+
+@pytest.mark.parametrize("hd", [256, 32])
+def test_main14b2_backward_vs_oracle(M, hd):
+    """every parameter gradient (and the input gradient of the Detector) of the deep-residual variant against the
+    oracle's CPU autograd, for a fixed random linear functional of delta and of the logits"""
+    dev = torch.device("cuda:0")
+    torch.manual_seed(42)
+    G, D = M.Generator(hidden_dim=hd), M.Detector()
+    gsd = {k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in G.state_dict().items()}
+    dsd = {k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in D.state_dict().items()}
+    G.to(dev).train(); D.to(dev).train()
+    B, T = 2, 8000
+    s = O.synthetic_clips(B, seed=21, T=T)
+    msg = torch.tensor([7, 7])                      # duplicate rows exercise the embedding scatter-add
+    r1, r2 = rnd(B, 1, T, seed=22), rnd(B, 17, T, seed=23)
+    # oracle
+    d_ref = O2.generator_forward(gsd, s, msg)
+    x_in = (s + d_ref.detach()).requires_grad_()
+    lg_ref = O2.detector_forward(dsd, x_in)
+    ((d_ref * r1).sum() + (lg_ref * r2).sum()).backward()
+    # HIP
+    d = G(s.to(dev), msg.to(dev))
+    x_in_h = (s.to(dev) + d.detach()).requires_grad_()
+    lg = D(x_in_h)
+    assert rel(d, d_ref) <= TOL and rel(lg, lg_ref) <= TOL
+    ((d * r1.to(dev)).sum() + (lg * r2.to(dev)).sum()).backward()
+    assert rel(x_in_h.grad, x_in.grad) <= 2e-3, "detector input gradient"
+    worst = ("", 0.0)
+    for name, mod, ref in (("G", G, gsd), ("D", D, dsd)):
+        for k, p in mod.named_parameters():
+            assert p.grad is not None, f"{name}.{k} has no gradient"
+            e = rel(p.grad, ref[k].grad)
+            if e > worst[1]:
+                worst = (f"{name}.{k}", e)
+            assert e <= 2e-3, f"{name}.{k}: grad rel err {e:.3e}"
+    print("worst grad rel err", worst)
