@@ -333,3 +333,38 @@ def _gconv(x, w, bias=None, stride=1, padding=0, act=0, res=None, vec=None):
 def _gconvT(x, w, bias, st):
     with torch.no_grad():
         return ConvTFn.apply(x, w, bias, st)
+
+
+# ------------------------------------------------------------------------------------------ step recipe
+LOSS_WEIGHTS = dict(l1=0.1, mel=2.0, loud=10.0, loc=10.0, bce=1.0)      # py/main14b_2.py:34-38
+
+
+def forward_losses(generator, detector, s, message):
+    """loop body of train_one_epoch, py/main14b_2.py:300-352: s_w is clamped to +-1 (:305), logits are channel-first,
+    no FIR / RMS / HF terms"""
+    from collections import OrderedDict
+    from . import losses as L
+    delta = generator(s, message)
+    s_w = L.clamp_peak(s + delta, 1.0)                                   # torch.clamp(s_w, -1, 1)
+    logits = detector(torch.cat([s_w, s], dim=0))                        # (2B, 1+bits, T)
+    loc, bce = L.detection_losses(logits.permute(0, 2, 1).contiguous(), message)
+    l1 = L.l1_to_zero(delta)
+    mel = L.MultiScaleMelLoss()(s, s_w)
+    loud = L.TFLoudnessLoss()(s, s_w)
+    w = LOSS_WEIGHTS
+    raw = l1 + mel + loud + loc + bce
+    total = w["l1"] * l1 + w["mel"] * mel + w["loud"] * loud + w["loc"] * loc + w["bce"] * bce
+    return total, OrderedDict(delta=delta, s_w=s_w, logits=logits, l1=l1, mel=mel, loud=loud, loc=loc, bce=bce,
+                              raw_total=raw, total=total)
+
+
+def train_step(generator, detector, optimizer, s, message, grad_sync=None):
+    optimizer.zero_grad(set_to_none=not hasattr(optimizer, "flat"))
+    total, out = forward_losses(generator, detector, s, message)
+    total.backward()
+    if hasattr(optimizer, "finish_backward"):
+        optimizer.finish_backward()
+    if grad_sync is not None:
+        grad_sync()
+    optimizer.step()
+    return out

@@ -104,6 +104,9 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=256, help="clips per GPU (BASELINE configs[2]/[3]: 256)")
+    ap.add_argument("--model", choices=["main16", "main14b_2"], default="main16",
+                    help="main16: BASELINE configs[2]/[3] (default, the headline metric); main14b_2: configs[4] "
+                         "(deep-residual variant, hidden_dim=256, default --batch 128)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--torch-adam", action="store_true", help="use torch.optim.Adam instead of the fused flat Adam")
     args = ap.parse_args()
@@ -127,7 +130,15 @@ def main():
     awm_amd.lib.load()                                  # fail loudly if the HIP library is missing
 
     torch.manual_seed(42)                               # weights: PyTorch default init under manual_seed(42)
-    G, D = awm_amd.Generator(16), awm_amd.Detector(16)
+    if args.model == "main14b_2":
+        from awm_amd import main14b_2 as M14
+        if args.batch == 256:
+            args.batch = 128                            # BASELINE configs[4]: batch 128 per GPU
+        G, D = M14.Generator(hidden_dim=256), M14.Detector()
+        step_fn = M14.train_step
+    else:
+        G, D = awm_amd.Generator(16), awm_amd.Detector(16)
+        step_fn = awm_amd.train_step
     G.to(dev).train(); D.to(dev).train()
     wmd.broadcast_parameters([G, D])
     if args.torch_adam:
@@ -142,7 +153,7 @@ def main():
     timer = LaunchTimer(awm_amd.lib, "wm_conv64", lambda a: a[14] == 3 and a[16] == 0)
 
     def step():
-        return awm_amd.train_step(G, D, opt, s, msg, grad_sync=sync)
+        return step_fn(G, D, opt, s, msg, grad_sync=sync)
 
     for _ in range(args.warmup):
         step()
@@ -196,16 +207,21 @@ def main():
                         "algorithmic_flops_per_launch": flops_launch, "algorithmic_bytes_per_launch": bytes_launch,
                         "hbm_achieved_GBs": round(bytes_launch / (k_ms * 1e-3) / 1e9, 1),
                         "hbm_frac_of_8TBs": round(bytes_launch / (k_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
+        if args.model == "main14b_2":
+            roofline = None        # the generic-shape kernels of config 5 are correctness-first; no roofline claim yet
+        workload = (f"main16 train step: Generator+Detector+6 losses fwd-bwd + Adam, B={args.batch} clips/GPU x {world} GPU, "
+                    f"1-s @ 16 kHz, message_bits=16 (BASELINE configs[{2 if world == 1 else 3}])") if args.model == "main16" else \
+                   (f"main14b_2 deep-residual train step (hidden_dim=256, 2-layer LSTM): Generator+Detector+5 losses fwd-bwd + Adam, "
+                    f"B={args.batch} clips/GPU x {world} GPU (BASELINE configs[4])")
         line = {"metric": "1-s@16kHz clips/sec (gen+det+loss fwd-bwd)", "value": round(value, 2), "unit": "clips/s",
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 3),
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-                "config": {"workload": f"main16 train step: Generator+Detector+6 losses fwd-bwd + Adam, B={args.batch} clips/GPU "
-                                       f"x {world} GPU, 1-s @ 16 kHz, message_bits=16 (BASELINE configs[{2 if world == 1 else 3}])",
+                "config": {"workload": workload,
                            "batch_per_gpu": args.batch, "global_batch": args.batch * world, "clip_len": T,
                            "optimizer": "torch.optim.Adam" if args.torch_adam else "fused flat Adam (wm_adam_step)",
                            "parallelism": f"dp{world}" if world > 1 else "single"},
                 "loss": round(total_loss, 6), "roofline": roofline}
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.model == "main16":
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -78,3 +78,29 @@ def detector_forward(sd: State, x: Tensor) -> Tensor:
     y = _decoder(sd, "upsample_blocks", y)
     y = F.conv1d(y, sd["final_conv.weight"], sd["final_conv.bias"], padding=3)
     return _fit_length(y, T)
+
+
+# loss weights, py/main14b_2.py:34-38
+LAMBDA_L1, LAMBDA_MSSPEC, LAMBDA_LOUD, LAMBDA_LOC, LAMBDA_DEC = 0.1, 2.0, 10.0, 10.0, 1.0
+
+
+def step_losses(gsd: State, dsd: State, s: Tensor, message: Tensor):
+    """The loop body of train_one_epoch, py/main14b_2.py:300-352 (clamped s_w, channel-first logits, five loss terms)."""
+    from collections import OrderedDict
+    from . import wm_oracle as O
+    B, T = s.shape[0], s.shape[-1]
+    delta = generator_forward(gsd, s, message)
+    s_w = torch.clamp(s + delta, -1.0, 1.0)
+    logits = detector_forward(dsd, torch.cat([s_w, s], dim=0))
+    det, dec = logits[:, 0, :], logits[:B, 1:, :]
+    tgt = torch.cat([torch.ones(B, T), torch.zeros(B, T)], dim=0).to(s.dtype)
+    loc = F.binary_cross_entropy_with_logits(det, tgt)
+    bits = O.message_bits_target(message, dec.shape[1]).to(s.dtype).unsqueeze(2).expand(-1, -1, T)
+    bce = F.binary_cross_entropy_with_logits(dec, bits)
+    l1 = delta.abs().mean()
+    mel = O.mel_loss(s, s_w)
+    loud = O.loudness_loss(s, s_w)
+    raw = l1 + mel + loud + loc + bce
+    total = LAMBDA_L1 * l1 + LAMBDA_MSSPEC * mel + LAMBDA_LOUD * loud + LAMBDA_LOC * loc + LAMBDA_DEC * bce
+    return total, OrderedDict(delta=delta, s_w=s_w, logits=logits, l1=l1, mel=mel, loud=loud, loc=loc, bce=bce,
+                              raw_total=raw, total=total)

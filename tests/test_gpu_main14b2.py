@@ -124,3 +124,25 @@ def test_main14b2_backward_vs_oracle(M, hd):
                 worst = (f"{name}.{k}", e)
             assert e <= 2e-3, f"{name}.{k}: grad rel err {e:.3e}"
     print("worst grad rel err", worst)
+
+
+def test_main14b2_train_step_vs_oracle(M):
+    """config-5 step recipe (clamped s_w, channel-first logits, 5 weighted loss terms): values and a few gradients"""
+    dev = torch.device("cuda:0")
+    torch.manual_seed(42)
+    G, D = M.Generator(hidden_dim=256), M.Detector()
+    gsd = {k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in G.state_dict().items()}
+    dsd = {k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in D.state_dict().items()}
+    G.to(dev).train(); D.to(dev).train()
+    s = O.synthetic_clips(2, seed=31)
+    msg = torch.tensor([123, 45678])
+    tot_r, out_r = O2.step_losses(gsd, dsd, s, msg)
+    tot_r.backward()
+    tot, out = M.forward_losses(G, D, s.to(dev), msg.to(dev))
+    tot.backward()
+    for k in ("l1", "mel", "loud", "loc", "bce", "raw_total", "total"):
+        assert rel(out[k].reshape(1), out_r[k].reshape(1)) <= TOL, k
+    assert rel(out["logits"], out_r["logits"]) <= TOL
+    for name, mod, ref in (("G", G, gsd), ("D", D, dsd)):
+        for k, p in mod.named_parameters():
+            assert rel(p.grad, ref[k].grad) <= 3e-3, f"{name}.{k}"
