@@ -156,8 +156,8 @@ __global__ __launch_bounds__(64) void lstm_h_step_fwd_kernel(const float* xp, co
 template <int KMAX>
 __global__ __launch_bounds__(256) void gwgrad_kernel(const float* __restrict__ A, const float* __restrict__ Bx,
                                                      float* __restrict__ G, float* __restrict__ dbias, int NB, int Ca, int Cb,
-                                                     int La, int Lb, int K, int S, int P) {
-    constexpr int TC = 64;
+                                                     int La, int Lb, int K, int S, int P, int TC) {
+    // TC = positions per LDS chunk (multiple of 64, chosen by the launcher from the LDS budget: 256 / 128 / 64)
     extern __shared__ __align__(16) float smem[];
     const int BW = (TC - 1) * S + K;            // Bx span of a chunk
     const int AS = TC + 1, BS = BW | 1;         // odd strides: operands are read down a column
@@ -190,11 +190,12 @@ __global__ __launch_bounds__(256) void gwgrad_kernel(const float* __restrict__ A
             Bs[r * BS + j] = (b < Cb && u >= 0 && u < Lb) ? v : 0.f;
         }
         __syncthreads();
-        // wave `wave` takes positions [16*wave, 16*wave+16) of the chunk: 8 k-steps of 2 positions
-        const float* ap = As + l31 * AS + 16 * wave + half;
-        const float* bp = Bs + l31 * BS + (16 * wave + half) * S;
-#pragma unroll
-        for (int s = 0; s < 8; ++s) {
+        // wave `wave` takes a quarter of the chunk: TC/8 k-steps of 2 positions
+        const int wq = TC / 4;
+        const float* ap = As + l31 * AS + wq * wave + half;
+        const float* bp = Bs + l31 * BS + (wq * wave + half) * S;
+#pragma unroll 4
+        for (int s = 0; s < wq / 2; ++s) {
             const float av = ap[2 * s];
 #pragma unroll
             for (int k = 0; k < KMAX; ++k)
@@ -248,12 +249,12 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restric
     __shared__ float scratch[4];
     const int c = blockIdx.x;
     float s = 0.f;
-    for (int nb = 0; nb < NB; ++nb) {
+    for (int nb = blockIdx.y; nb < NB; nb += gridDim.y) {
         const float* r = x + ((size_t)nb * C + c) * L;
         for (int t = threadIdx.x; t < L; t += 256) s += r[t];
     }
     s = block_sum<4>(s, scratch);
-    if (threadIdx.x == 0) out[c] += s;
+    if (threadIdx.x == 0) atomicAdd(out + c, s);
 }
 
 // out[row] = sum_t x[row][t] for any row length
@@ -306,12 +307,15 @@ int wm_permute_acl(const float* x, float* y, int A, int C, int L, hipStream_t st
 int wm_gwgrad(const float* A, const float* Bx, float* G, float* dbias, int NB, int Ca, int Cb, int La, int Lb, int K, int S,
               int P, hipStream_t stream) {
     if (NB <= 0 || Ca <= 0 || Cb <= 0 || La <= 0 || K <= 0 || K > 16 || S <= 0 || S > 8) return (int)hipErrorInvalidValue;
-    const int nchunks = (La + 63) / 64, nwork = NB * nchunks;
+    int TC = 256;                                  // positions per LDS chunk, limited by a 90 KB LDS budget
+    while (TC > 64 && (size_t)(32 * (TC + 1) + 32 * (((TC - 1) * S + K) | 1)) * sizeof(float) > 90 * 1024) TC >>= 1;
+    if (La <= 64) TC = 64;
+    const int nchunks = (La + TC - 1) / TC, nwork = NB * nchunks;
     const int tiles = ((Ca + 31) / 32) * ((Cb + 31) / 32);
     int gz = (2048 + tiles - 1) / tiles;          // ~2048 workgroups in flight overall
     if (gz > nwork) gz = nwork;
     if (gz < 1) gz = 1;
-    const size_t lds = (size_t)(32 * 65 + 32 * ((63 * S + K) | 1)) * sizeof(float);
+    const size_t lds = (size_t)(32 * (TC + 1) + 32 * (((TC - 1) * S + K) | 1)) * sizeof(float);
     dim3 grid((Ca + 31) / 32, (Cb + 31) / 32, gz);
     static bool done = false;
     if (!done) {
@@ -320,9 +324,9 @@ int wm_gwgrad(const float* A, const float* Bx, float* G, float* dbias, int NB, i
         WM_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gwgrad_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
         done = true;
     }
-    if (K <= 4) hipLaunchKernelGGL(gwgrad_kernel<4>, grid, dim3(256), lds, stream, A, Bx, G, dbias, NB, Ca, Cb, La, Lb, K, S, P);
-    else if (K <= 8) hipLaunchKernelGGL(gwgrad_kernel<8>, grid, dim3(256), lds, stream, A, Bx, G, dbias, NB, Ca, Cb, La, Lb, K, S, P);
-    else hipLaunchKernelGGL(gwgrad_kernel<16>, grid, dim3(256), lds, stream, A, Bx, G, dbias, NB, Ca, Cb, La, Lb, K, S, P);
+    if (K <= 4) hipLaunchKernelGGL(gwgrad_kernel<4>, grid, dim3(256), lds, stream, A, Bx, G, dbias, NB, Ca, Cb, La, Lb, K, S, P, TC);
+    else if (K <= 8) hipLaunchKernelGGL(gwgrad_kernel<8>, grid, dim3(256), lds, stream, A, Bx, G, dbias, NB, Ca, Cb, La, Lb, K, S, P, TC);
+    else hipLaunchKernelGGL(gwgrad_kernel<16>, grid, dim3(256), lds, stream, A, Bx, G, dbias, NB, Ca, Cb, La, Lb, K, S, P, TC);
     WM_CHECK_LAUNCH();
     return 0;
 }
@@ -341,7 +345,7 @@ int wm_lstm_h_step_bwd(float* gates, const float* c, const float* cprev, const f
 }
 
 int wm_channel_sum(const float* x, float* out, int NB, int C, int L, hipStream_t stream) {
-    hipLaunchKernelGGL(channel_sum_kernel, dim3(C), dim3(256), 0, stream, x, out, NB, C, L);
+    hipLaunchKernelGGL(channel_sum_kernel, dim3(C, NB < 64 ? NB : 64), dim3(256), 0, stream, x, out, NB, C, L);
     WM_CHECK_LAUNCH();
     return 0;
 }
