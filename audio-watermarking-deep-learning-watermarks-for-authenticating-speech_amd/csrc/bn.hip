@@ -127,10 +127,17 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __re
     const int c = threadIdx.x;
     const double mu = save_mean[c], is = save_invstd[c], ga = gamma[c];
     const double sxh = (s2 - mu * s1) * is;            // sum dz * yhat
-    A[c] = (float)(ga * is);
-    // eval mode: the statistics are constants (running stats), only the scale survives
-    Cc[c] = eval_mode ? 0.f : (float)(-ga * is * is * sxh / count);
-    Bc[c] = eval_mode ? 0.f : (float)(-ga * is * s1 / count + ga * is * is * mu * sxh / count);
+    // dy = A*dz + Cc*y + B must sum to zero over the batch (that is what BatchNorm backward guarantees); with fp32
+    // constants the rounding of A, Cc and B would leave a *systematic* residue N*eps that lands in every upstream
+    // "sum" gradient (biases, betas).  So B is derived from the ROUNDED A and Cc and handed over as hi + lo words.
+    const float Af = (float)(ga * is);
+    const float Cf = eval_mode ? 0.f : (float)(-ga * is * is * sxh / count);     // eval: statistics are constants
+    const double Bd = eval_mode ? 0.0 : -((double)Af * s1 + (double)Cf * (mu * count)) / count;
+    const float Bh = (float)Bd;
+    A[c] = Af;
+    Cc[c] = Cf;
+    Bc[c] = Bh;
+    Bc[64 + c] = (float)(Bd - (double)Bh);
     if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)sxh : (float)sxh;
     if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)s1 : (float)s1;
 }

@@ -45,10 +45,10 @@ struct Conv64Args {
 };
 
 template <int PRO>
-__device__ __forceinline__ float pro_apply(float v, float v2, float ca, float cb, float cc) {
+__device__ __forceinline__ float pro_apply(float v, float v2, float ca, float cb, float cc, float cl = 0.f) {
     if (PRO == PRO_BNRELU) return fmaxf(fmaf(v, ca, cb), 0.f);
     if (PRO == PRO_ADDVEC) return v + ca;
-    if (PRO == PRO_BNBWD) return fmaf(ca, v, fmaf(cc, v2, cb));
+    if (PRO == PRO_BNBWD) return fmaf(ca, v, fmaf(cc, v2, cb)) + cl;      // cb + cl: offset as hi + lo words (pb[0..63], pb[64..127])
     return v;
 }
 
@@ -110,12 +110,12 @@ __global__ __launch_bounds__(256) void conv64_kernel(Conv64Args a) {
             float4 v = st[i];
             if (PRO != PRO_NONE) {
                 const float ca = (PRO == PRO_ADDVEC) ? a.pa[b * 64 + c] : Cs[c];
-                const float cb = Cs[64 + c], cc = Cs[128 + c];
+                const float cb = Cs[64 + c], cc = Cs[128 + c], cl = TWO ? Cs[192 + c] : 0.f;
                 const float4 w = TWO ? st2[i] : v;
-                v.x = pro_apply<PRO>(v.x, w.x, ca, cb, cc);
-                v.y = pro_apply<PRO>(v.y, w.y, ca, cb, cc);
-                v.z = pro_apply<PRO>(v.z, w.z, ca, cb, cc);
-                v.w = pro_apply<PRO>(v.w, w.w, ca, cb, cc);
+                v.x = pro_apply<PRO>(v.x, w.x, ca, cb, cc, cl);
+                v.y = pro_apply<PRO>(v.y, w.y, ca, cb, cc, cl);
+                v.z = pro_apply<PRO>(v.z, w.z, ca, cb, cc, cl);
+                v.w = pro_apply<PRO>(v.w, w.w, ca, cb, cc, cl);
             }
             if (t >= T) v = make_float4(0.f, 0.f, 0.f, 0.f);     // T % 4 == 0: a float4 is all in or all out
             *reinterpret_cast<float4*>(Xs + c * XS + 4 + 4 * q) = v;
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void conv64_kernel(Conv64Args a) {
                 float v = hl[i];
                 if (PRO != PRO_NONE) {
                     const float ca = (PRO == PRO_ADDVEC) ? a.pa[b * 64 + c] : Cs[c];
-                    v = pro_apply<PRO>(v, TWO ? hl2[i] : v, ca, Cs[64 + c], Cs[128 + c]);
+                    v = pro_apply<PRO>(v, TWO ? hl2[i] : v, ca, Cs[64 + c], Cs[128 + c], TWO ? Cs[192 + c] : 0.f);
                 }
                 if (t < 0 || t >= T) v = 0.f;
                 Xs[c * XS + ((h < PAD) ? 4 - PAD + h : 4 + NT + (h - PAD))] = v;
@@ -382,12 +382,12 @@ __global__ __launch_bounds__(256) void wgrad64_kernel(Wgrad64Args a) {
             const int idx = tid + i * 256, c = idx / QR, q = idx % QR, t = t0 + 4 * q;
             float4 v = sg[i], u = sx[i];
             if (GPRO == PRO_BNBWD) {
-                const float ca = Cs[c], cb = Cs[64 + c], cc = Cs[128 + c];
+                const float ca = Cs[c], cb = Cs[64 + c], cc = Cs[128 + c], cl = Cs[320 + c];
                 const float4 w = sg2[i];
-                v.x = pro_apply<PRO_BNBWD>(v.x, w.x, ca, cb, cc);
-                v.y = pro_apply<PRO_BNBWD>(v.y, w.y, ca, cb, cc);
-                v.z = pro_apply<PRO_BNBWD>(v.z, w.z, ca, cb, cc);
-                v.w = pro_apply<PRO_BNBWD>(v.w, w.w, ca, cb, cc);
+                v.x = pro_apply<PRO_BNBWD>(v.x, w.x, ca, cb, cc, cl);
+                v.y = pro_apply<PRO_BNBWD>(v.y, w.y, ca, cb, cc, cl);
+                v.z = pro_apply<PRO_BNBWD>(v.z, w.z, ca, cb, cc, cl);
+                v.w = pro_apply<PRO_BNBWD>(v.w, w.w, ca, cb, cc, cl);
             }
             if (XPRO != PRO_NONE) {
                 const float ca = (XPRO == PRO_ADDVEC) ? a.xa[b * 64 + c] : Cs[192 + c];
@@ -427,6 +427,7 @@ __global__ __launch_bounds__(256) void wgrad64_kernel(Wgrad64Args a) {
         Cs[128 + tid] = GTWO ? a.gc[tid] : 0.f;
         Cs[192 + tid] = (XPRO == PRO_BNRELU) ? a.xa[tid] : 0.f;
         Cs[256 + tid] = (XPRO == PRO_BNRELU) ? a.xb[tid] : 0.f;
+        Cs[320 + tid] = GTWO ? a.gb[64 + tid] : 0.f;        // low word of the BatchNorm-backward offset
     }
     __syncthreads();
     if (tile < ntiles) write_tile(tile);
@@ -519,7 +520,7 @@ __global__ __launch_bounds__(256) void wgrad64_kernel(Wgrad64Args a) {
 template <int KW, int GPRO, int XPRO>
 int launch_wgrad64(const Wgrad64Args& a, int* grid_out, hipStream_t stream) {
     constexpr int NT = 128;
-    constexpr size_t lds = (size_t)(64 * (NT + 4) + 64 * (NT + 8) + 5 * 64) * sizeof(float);
+    constexpr size_t lds = (size_t)(64 * (NT + 4) + 64 * (NT + 8) + 6 * 64) * sizeof(float);
     static bool attr_done = false;
     auto kern = wgrad64_kernel<KW, GPRO, XPRO>;
     if (!attr_done) {
@@ -541,8 +542,9 @@ __global__ void wgrad64_reduce_kernel(const float* __restrict__ partial, int npa
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int stride = KW * 4096 + 64;
     if (i >= stride) return;
-    float s = 0.f;
-    for (int p = 0; p < nparts; ++p) s += partial[(size_t)p * stride + i];
+    double sd = 0.0;                                    // fixed order, fp64: bitwise reproducible and cancellation-safe
+    for (int p = 0; p < nparts; ++p) sd += (double)partial[(size_t)p * stride + i];
+    const float s = (float)sd;
     if (i < KW * 4096) {
         const int tap = i / 4096, out = (i / 64) % 64, in = i % 64;
         const int dst = (mode == 0) ? (out * 64 + in) * KW + tap : (in * 64 + out) * KW + (KW - 1 - tap);
@@ -551,6 +553,454 @@ __global__ void wgrad64_reduce_kernel(const float* __restrict__ partial, int npa
         const int c = i - KW * 4096;
         dbias[c] = accumulate ? dbias[c] + s : s;
     }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// bf16x6 variant of the k3 convolution: fp32-grade results on the bf16 matrix cores.
+// Every fp32 operand is split into three bf16 pieces (x = hi + mid + lo exactly to 24 bits) when it is staged
+// into LDS; a product a*b is the sum of the six piece products of weight >= 2^-16 (hi*hi, hi*mid, mid*hi, hi*lo,
+// lo*hi, mid*mid), accumulated in fp32 by v_mfma_f32_32x32x16_bf16.  The dropped terms are <= 2^-24 relative, i.e.
+// the result carries the same error as a native fp32 FMA chain, at 6/16 of the matrix-pipe time of
+// v_mfma_f32_32x32x2_f32 -- and, unlike the fp32 MFMA, the bf16 MFMA does not share the SIMD's VALU pipe.
+// LDS images are channel-minor ([time][channel] and [tap][cout][cin], 144-B pitch) so that an MFMA fragment
+// (8 consecutive k = 8 input channels) is one aligned ds_read_b128.
+// ---------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void split3_pair(float a, float b, unsigned& p0, unsigned& p1, unsigned& p2) {
+    bf16x2 h = {(__bf16)a, (__bf16)b};
+    p0 = __builtin_bit_cast(unsigned, h);
+    a -= __uint_as_float(p0 << 16); b -= __uint_as_float(p0 & 0xffff0000u);
+    bf16x2 m = {(__bf16)a, (__bf16)b};
+    p1 = __builtin_bit_cast(unsigned, m);
+    a -= __uint_as_float(p1 << 16); b -= __uint_as_float(p1 & 0xffff0000u);
+    bf16x2 l = {(__bf16)a, (__bf16)b};
+    p2 = __builtin_bit_cast(unsigned, l);
+}
+
+template <int PRO, int EPI, bool STATS>
+__global__ __launch_bounds__(256) void conv64bf_kernel(Conv64Args a) {
+    constexpr int KW = 3, PAD = 1, NT = 128, ROWS = NT + 2, PITCH = 72, NP = 3;
+    constexpr int NC = 4;                         // (channel pair, time quad) combos per thread
+    constexpr bool TWO = (PRO == PRO_BNBWD);
+    constexpr bool E1 = (EPI == EPI_RELUMASK || EPI == EPI_ADD);
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    unsigned short* Wb = reinterpret_cast<unsigned short*>(smem_raw);              // [NP][KW][64 out][PITCH]
+    unsigned short* Xb = Wb + NP * KW * 64 * PITCH;                                // [NP][ROWS][PITCH]
+    float* Cs = reinterpret_cast<float*>(Xb + NP * ROWS * PITCH);                  // [6][64]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const int T = a.T;
+    const int tilesPerClip = (T + NT - 1) / NT, ntiles = a.B * tilesPerClip;
+
+    float4 sa[NC], sb[NC], sa2[TWO ? NC : 1], sb2[TWO ? NC : 1];
+    float hl, hl2 = 0.f;
+    // staging map: a wave covers 8 channel pairs x 8 time quads (128-B global segments, 2-way LDS write conflicts)
+    auto combo = [&](int i, int& cp, int& q) {
+        const int idx = tid + i * 256, widx = idx >> 6, l = idx & 63;
+        cp = (widx & 3) * 8 + (l & 7);
+        q = (widx >> 2) * 8 + (l >> 3);
+    };
+    auto load_tile = [&](int tile) {              // branch-free: clamped addresses, masked when written to LDS
+        const int b = tile / tilesPerClip, t0 = (tile - b * tilesPerClip) * NT;
+        const float* xb = a.x + (size_t)b * 64 * T;
+        const float* xb2 = TWO ? a.x2 + (size_t)b * 64 * T : nullptr;
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            int cp, q;
+            combo(i, cp, q);
+            const size_t o = (size_t)(2 * cp) * T + min(t0 + 4 * q, T - 4);
+            sa[i] = *reinterpret_cast<const float4*>(xb + o);
+            sb[i] = *reinterpret_cast<const float4*>(xb + o + T);
+            if (TWO) { sa2[i] = *reinterpret_cast<const float4*>(xb2 + o); sb2[i] = *reinterpret_cast<const float4*>(xb2 + o + T); }
+        }
+        const int hc = (tid & 127) >> 1, hh = tid & 1;
+        const int ht = min(max(hh ? t0 + NT : t0 - 1, 0), T - 1);
+        hl = xb[(size_t)hc * T + ht];
+        if (TWO) hl2 = xb2[(size_t)hc * T + ht];
+    };
+    auto write_tile = [&](int tile) {
+        const int b = tile / tilesPerClip, t0 = (tile - b * tilesPerClip) * NT;
+        unsigned* X32 = reinterpret_cast<unsigned*>(Xb);
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            int cp, q;
+            combo(i, cp, q);
+            const int c = 2 * cp, t = t0 + 4 * q;
+            float va[4] = {sa[i].x, sa[i].y, sa[i].z, sa[i].w}, vb[4] = {sb[i].x, sb[i].y, sb[i].z, sb[i].w};
+            if (PRO != PRO_NONE) {
+                const float ca0 = (PRO == PRO_ADDVEC) ? a.pa[b * 64 + c] : Cs[c], ca1 = (PRO == PRO_ADDVEC) ? a.pa[b * 64 + c + 1] : Cs[c + 1];
+                const float cb0 = Cs[64 + c], cb1 = Cs[64 + c + 1], cc0 = Cs[128 + c], cc1 = Cs[128 + c + 1];
+                const float cl0 = TWO ? Cs[192 + c] : 0.f, cl1 = TWO ? Cs[192 + c + 1] : 0.f;
+                float wa[4] = {0.f, 0.f, 0.f, 0.f}, wb[4] = {0.f, 0.f, 0.f, 0.f};
+                if (TWO) { wa[0] = sa2[i].x; wa[1] = sa2[i].y; wa[2] = sa2[i].z; wa[3] = sa2[i].w; wb[0] = sb2[i].x; wb[1] = sb2[i].y; wb[2] = sb2[i].z; wb[3] = sb2[i].w; }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { va[e] = pro_apply<PRO>(va[e], wa[e], ca0, cb0, cc0, cl0); vb[e] = pro_apply<PRO>(vb[e], wb[e], ca1, cb1, cc1, cl1); }
+            }
+            const bool ok = t < T;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                unsigned p0, p1, p2;
+                split3_pair(ok ? va[e] : 0.f, ok ? vb[e] : 0.f, p0, p1, p2);
+                const int o = ((1 + 4 * q + e) * PITCH + c) >> 1;
+                X32[o] = p0; X32[(ROWS * PITCH >> 1) + o] = p1; X32[2 * (ROWS * PITCH >> 1) + o] = p2;
+            }
+        }
+        if (tid < 128) {
+            const int hc = tid >> 1, hh = tid & 1, t = hh ? t0 + NT : t0 - 1;
+            float v = hl;
+            if (PRO != PRO_NONE) {
+                const float ca = (PRO == PRO_ADDVEC) ? a.pa[b * 64 + hc] : Cs[hc];
+                v = pro_apply<PRO>(v, hl2, ca, Cs[64 + hc], Cs[128 + hc], TWO ? Cs[192 + hc] : 0.f);
+            }
+            if (t < 0 || t >= T) v = 0.f;
+            unsigned p0, p1, p2;
+            split3_pair(v, 0.f, p0, p1, p2);
+            const int o = (hh ? NT + 1 : 0) * PITCH + hc;
+            Xb[o] = (unsigned short)p0; Xb[ROWS * PITCH + o] = (unsigned short)p1; Xb[2 * ROWS * PITCH + o] = (unsigned short)p2;
+        }
+    };
+
+    int tile = blockIdx.x;
+    if (tile < ntiles) load_tile(tile);
+    // resident weights: global image [NP][KW][64][64] bf16 -> LDS pitch 72, 16 B at a time
+    for (int i = tid; i < NP * KW * 64 * 8; i += 256) {
+        const int row = i >> 3, seg = i & 7;
+        *reinterpret_cast<uint4*>(Wb + row * PITCH + seg * 8) = reinterpret_cast<const uint4*>(a.wp)[i];
+    }
+    if (tid < 64) {
+        Cs[tid] = (PRO == PRO_BNRELU || PRO == PRO_BNBWD) ? a.pa[tid] : 0.f;
+        Cs[64 + tid] = (PRO == PRO_BNRELU || PRO == PRO_BNBWD) ? a.pb[tid] : 0.f;
+        Cs[128 + tid] = (PRO == PRO_BNBWD) ? a.pc[tid] : 0.f;
+        Cs[192 + tid] = (PRO == PRO_BNBWD) ? a.pb[64 + tid] : ((EPI == EPI_BIAS && a.bias) ? a.bias[tid] : 0.f);
+        Cs[256 + tid] = (EPI == EPI_RELUMASK) ? a.ea[tid] : 0.f;
+        Cs[320 + tid] = (EPI == EPI_RELUMASK) ? a.eb[tid] : 0.f;
+    }
+    __syncthreads();
+    if (tile < ntiles) write_tile(tile);
+    __syncthreads();
+
+    float s1[STATS ? 32 : 1], s2[STATS ? 32 : 1];
+    if (STATS) {
+#pragma unroll
+        for (int j = 0; j < 32; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+    }
+    while (tile < ntiles) {
+        const int next = tile + gridDim.x;
+        if (next < ntiles) load_tile(next);
+        const int b = tile / tilesPerClip, t0 = (tile - b * tilesPerClip) * NT;
+        const int tcol = t0 + wave * 32 + l31;
+        float e1r[E1 ? 32 : 1];
+        if (E1) {
+            const float* eb1 = a.e1 + (size_t)b * 64 * T + min(tcol, T - 1);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) e1r[mt * 16 + r] = eb1[(size_t)(mt * 32 + mfma_row(r, half)) * T];
+        }
+        f32x16 acc[2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+        const unsigned short* wbase = Wb + l31 * PITCH + 8 * half;
+        const unsigned short* xbase = Xb + (wave * 32 + l31) * PITCH + 8 * half;
+#pragma unroll 1
+        for (int tap = 0; tap < KW; ++tap) {
+#pragma unroll
+            for (int ch = 0; ch < 4; ++ch) {
+                bf16x8 A[2][NP], Bf[NP];
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    Bf[p] = *reinterpret_cast<const bf16x8*>(xbase + (p * ROWS + tap) * PITCH + 16 * ch);
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt)
+                        A[mt][p] = *reinterpret_cast<const bf16x8*>(wbase + ((p * KW + tap) * 64 + mt * 32) * PITCH + 16 * ch);
+                }
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[mt][1], Bf[1], acc[mt], 0, 0, 0);
+                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[mt][0], Bf[2], acc[mt], 0, 0, 0);
+                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[mt][2], Bf[0], acc[mt], 0, 0, 0);
+                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[mt][0], Bf[1], acc[mt], 0, 0, 0);
+                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[mt][1], Bf[0], acc[mt], 0, 0, 0);
+                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[mt][0], Bf[0], acc[mt], 0, 0, 0);
+                }
+            }
+        }
+        float* yb = a.y + (size_t)b * 64 * T + tcol;
+        const bool ok = tcol < T;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = mt * 32 + mfma_row(r, half);
+                float v = acc[mt][r];
+                float q = 0.f;
+                if (EPI == EPI_BIAS) v += Cs[192 + co];
+                if (EPI == EPI_RELUMASK) { q = e1r[mt * 16 + r]; v = (fmaf(q, Cs[256 + co], Cs[320 + co]) > 0.f) ? v : 0.f; }
+                if (EPI == EPI_ADD) v += e1r[mt * 16 + r];
+                if (ok) {
+                    yb[(size_t)co * T] = v;
+                    if (STATS) { s1[mt * 16 + r] += v; s2[mt * 16 + r] += (EPI == EPI_RELUMASK) ? v * q : v * v; }
+                }
+            }
+        __syncthreads();
+        if (next < ntiles) write_tile(next);
+        __syncthreads();
+        tile = next;
+    }
+    if (STATS) {
+        float* red = reinterpret_cast<float*>(Xb);          // [4 waves][2][64]
+#pragma unroll
+        for (int j = 0; j < 32; ++j) { s1[j] = half_wave_sum(s1[j]); s2[j] = half_wave_sum(s2[j]); }
+        if (l31 == 0) {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = mt * 32 + mfma_row(r, half);
+                    red[wave * 128 + co] = s1[mt * 16 + r];
+                    red[wave * 128 + 64 + co] = s2[mt * 16 + r];
+                }
+        }
+        __syncthreads();
+        if (tid < 128)
+            a.stats[(size_t)blockIdx.x * 128 + tid] = red[tid] + red[128 + tid] + red[256 + tid] + red[384 + tid];
+    }
+}
+
+template <int PRO, int EPI, bool STATS>
+int launch_conv64bf(const Conv64Args& a, hipStream_t stream) {
+    constexpr size_t lds = (size_t)(3 * 3 * 64 * 72 + 3 * 130 * 72) * 2 + 6 * 64 * sizeof(float);
+    static bool attr_done = false;
+    auto kern = conv64bf_kernel<PRO, EPI, STATS>;
+    if (!attr_done) {
+        WM_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    const int ntiles = a.B * ((a.T + 127) / 128);
+    const int grid = ntiles < kNumCU ? ntiles : kNumCU;
+    if (STATS && grid < kNumCU) WM_TRY(hipMemsetAsync(a.stats, 0, sizeof(float) * 128 * kNumCU, stream));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, a);
+    WM_CHECK_LAUNCH();
+    return 0;
+}
+
+// bf16 three-piece weight image [piece][tap][out][in] (uint16) for the k3 convolutions; mode as wm_pack_w64 (0 / 1)
+__global__ void pack_w64_bf_kernel(const float* __restrict__ w, unsigned short* __restrict__ wpb, int mode) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 3 * 4096) return;
+    const int tap = i / 4096, out = (i / 64) % 64, in = i % 64;
+    const float v = (mode == 0) ? w[(out * 64 + in) * 3 + tap] : w[(in * 64 + out) * 3 + (2 - tap)];
+    unsigned p0, p1, p2;
+    split3_pair(v, 0.f, p0, p1, p2);
+    wpb[i] = (unsigned short)p0; wpb[3 * 4096 + i] = (unsigned short)p1; wpb[2 * 3 * 4096 + i] = (unsigned short)p2;
+}
+
+// ---------------------------------------------------------------------------------------------
+// bf16x6 weight gradient of the k3 convolution.  The contraction runs over time, so both operands keep the natural
+// [channel][time] layout in LDS (one aligned ds_read_b128 = 8 consecutive time steps of a channel = one MFMA fragment,
+// no transposition).  The +-1 time shift of taps 0 and 2 is made in registers: the centre fragment plus the two
+// neighbouring elements are funnel-shifted with v_alignbit (VALU work that runs beside the bf16 MFMA pipe).
+// ---------------------------------------------------------------------------------------------
+template <int GPRO, int XPRO>
+__global__ __launch_bounds__(256) void wgrad64bf_kernel(Wgrad64Args a) {
+    constexpr int KW = 3, NT = 128, NP = 3, PG = 136, PX = 152, XO = 8;   // X element index = (t - t0) + XO
+    constexpr int QR = NT / 4, NV = 64 * QR / 256;
+    constexpr bool GTWO = (GPRO == PRO_BNBWD);
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    unsigned short* Gb = reinterpret_cast<unsigned short*>(smem_raw);          // [NP][64][PG]
+    unsigned short* Xb = Gb + NP * 64 * PG;                                    // [NP][64][PX]
+    float* Cs = reinterpret_cast<float*>(Xb + NP * 64 * PX);                   // [5][64]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const int T = a.T;
+    const int tilesPerClip = (T + NT - 1) / NT, ntiles = a.B * tilesPerClip;
+
+    float4 sg[NV], sg2[GTWO ? NV : 1], sx[NV];
+    float hx;
+    float bsum[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) bsum[i] = 0.f;
+
+    auto load_tile = [&](int tile) {            // branch-free
+        const int b = tile / tilesPerClip, t0 = (tile - b * tilesPerClip) * NT;
+        const size_t base = (size_t)b * 64 * T;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int idx = tid + i * 256, c = idx / QR, q = idx % QR;
+            const int t = min(t0 + 4 * q, T - 4);
+            sg[i] = *reinterpret_cast<const float4*>(a.g + base + (size_t)c * T + t);
+            if (GTWO) sg2[i] = *reinterpret_cast<const float4*>(a.g2 + base + (size_t)c * T + t);
+            sx[i] = *reinterpret_cast<const float4*>(a.x + base + (size_t)c * T + t);
+        }
+        const int hc = (tid & 127) >> 1, hh = tid & 1;
+        hx = a.x[base + (size_t)hc * T + min(max(hh ? t0 + NT : t0 - 1, 0), T - 1)];
+    };
+    auto put4 = [&](unsigned short* dst, int stride_p, float v0, float v1, float v2, float v3) {
+        unsigned a0, a1, a2, b0, b1, b2;
+        split3_pair(v0, v1, a0, a1, a2);
+        split3_pair(v2, v3, b0, b1, b2);
+        *reinterpret_cast<uint2*>(dst) = make_uint2(a0, b0);
+        *reinterpret_cast<uint2*>(dst + stride_p) = make_uint2(a1, b1);
+        *reinterpret_cast<uint2*>(dst + 2 * stride_p) = make_uint2(a2, b2);
+    };
+    auto write_tile = [&](int tile) {
+        const int b = tile / tilesPerClip, t0 = (tile - b * tilesPerClip) * NT;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int idx = tid + i * 256, c = idx / QR, q = idx % QR, t = t0 + 4 * q;
+            float4 v = sg[i], u = sx[i];
+            if (GPRO == PRO_BNBWD) {
+                const float ca = Cs[c], cb = Cs[64 + c], cc = Cs[128 + c], cl = Cs[320 + c];
+                const float4 w = sg2[i];
+                v.x = pro_apply<PRO_BNBWD>(v.x, w.x, ca, cb, cc, cl); v.y = pro_apply<PRO_BNBWD>(v.y, w.y, ca, cb, cc, cl);
+                v.z = pro_apply<PRO_BNBWD>(v.z, w.z, ca, cb, cc, cl); v.w = pro_apply<PRO_BNBWD>(v.w, w.w, ca, cb, cc, cl);
+            }
+            if (XPRO != PRO_NONE) {
+                const float ca = (XPRO == PRO_ADDVEC) ? a.xa[b * 64 + c] : Cs[192 + c];
+                const float cb = Cs[256 + c];
+                u.x = pro_apply<XPRO>(u.x, 0.f, ca, cb, 0.f); u.y = pro_apply<XPRO>(u.y, 0.f, ca, cb, 0.f);
+                u.z = pro_apply<XPRO>(u.z, 0.f, ca, cb, 0.f); u.w = pro_apply<XPRO>(u.w, 0.f, ca, cb, 0.f);
+            }
+            if (t >= T) { v = make_float4(0.f, 0.f, 0.f, 0.f); u = v; }
+            bsum[i] += (v.x + v.y) + (v.z + v.w);
+            put4(Gb + c * PG + 4 * q, 64 * PG, v.x, v.y, v.z, v.w);
+            put4(Xb + c * PX + XO + 4 * q, 64 * PX, u.x, u.y, u.z, u.w);
+        }
+        if (tid < 128) {
+            const int hc = tid >> 1, hh = tid & 1, t = hh ? t0 + NT : t0 - 1;
+            float v = hx;
+            if (XPRO != PRO_NONE) {
+                const float ca = (XPRO == PRO_ADDVEC) ? a.xa[b * 64 + hc] : Cs[192 + hc];
+                v = pro_apply<XPRO>(v, 0.f, ca, Cs[256 + hc], 0.f);
+            }
+            if (t < 0 || t >= T) v = 0.f;
+            unsigned p0, p1, p2;
+            split3_pair(v, 0.f, p0, p1, p2);
+            const int o = hc * PX + (hh ? XO + NT : XO - 1);
+            Xb[o] = (unsigned short)p0; Xb[64 * PX + o] = (unsigned short)p1; Xb[2 * 64 * PX + o] = (unsigned short)p2;
+        }
+    };
+
+    int tile = blockIdx.x;
+    if (tile < ntiles) load_tile(tile);
+    if (tid < 64) {
+        Cs[tid] = GTWO ? a.ga[tid] : 0.f;
+        Cs[64 + tid] = GTWO ? a.gb[tid] : 0.f;
+        Cs[128 + tid] = GTWO ? a.gc[tid] : 0.f;
+        Cs[192 + tid] = (XPRO == PRO_BNRELU) ? a.xa[tid] : 0.f;
+        Cs[256 + tid] = (XPRO == PRO_BNRELU) ? a.xb[tid] : 0.f;
+        Cs[320 + tid] = GTWO ? a.gb[64 + tid] : 0.f;        // low word of the BatchNorm-backward offset
+    }
+    // the element right of the right halo is read by the funnel shift of the last fragment: keep it defined
+    for (int i = tid; i < NP * 64; i += 256) Xb[i * PX + XO + NT + 1] = 0;
+    __syncthreads();
+    if (tile < ntiles) write_tile(tile);
+    __syncthreads();
+
+    f32x16 acc[KW][2][2];
+#pragma unroll
+    for (int k = 0; k < KW; ++k)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[k][mt][nt][r] = 0.f;
+
+    while (tile < ntiles) {
+        const int next = tile + gridDim.x;
+        if (next < ntiles) load_tile(next);
+#pragma unroll 1
+        for (int ss = 0; ss < 2; ++ss) {                 // this wave's 32 time steps = 2 k-blocks of 16
+            const int e0 = wave * 32 + ss * 16 + 8 * half;
+            bf16x8 A[2][NP];
+#pragma unroll
+            for (int p = 0; p < NP; ++p)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+                    A[mt][p] = *reinterpret_cast<const bf16x8*>(Gb + (p * 64 + mt * 32 + l31) * PG + e0);
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                bf16x8 Bc[NP], Bl[NP], Br[NP];
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    const unsigned short* xr = Xb + (p * 64 + nt * 32 + l31) * PX + XO + e0;
+                    const uint4 f = *reinterpret_cast<const uint4*>(xr);
+                    const unsigned L = *reinterpret_cast<const unsigned*>(xr - 2), R = *reinterpret_cast<const unsigned*>(xr + 8);
+                    const uint4 fl = make_uint4(__builtin_amdgcn_alignbit(f.x, L, 16), __builtin_amdgcn_alignbit(f.y, f.x, 16),
+                                                __builtin_amdgcn_alignbit(f.z, f.y, 16), __builtin_amdgcn_alignbit(f.w, f.z, 16));
+                    const uint4 fr = make_uint4(__builtin_amdgcn_alignbit(f.y, f.x, 16), __builtin_amdgcn_alignbit(f.z, f.y, 16),
+                                                __builtin_amdgcn_alignbit(f.w, f.z, 16), __builtin_amdgcn_alignbit(R, f.w, 16));
+                    Bc[p] = __builtin_bit_cast(bf16x8, f);
+                    Bl[p] = __builtin_bit_cast(bf16x8, fl);
+                    Br[p] = __builtin_bit_cast(bf16x8, fr);
+                }
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+#define WM_MM6(ACC, BB)                                                                              \
+    ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[mt][1], BB[1], ACC, 0, 0, 0);                     \
+    ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[mt][0], BB[2], ACC, 0, 0, 0);                     \
+    ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[mt][2], BB[0], ACC, 0, 0, 0);                     \
+    ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[mt][0], BB[1], ACC, 0, 0, 0);                     \
+    ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[mt][1], BB[0], ACC, 0, 0, 0);                     \
+    ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[mt][0], BB[0], ACC, 0, 0, 0);
+                    WM_MM6(acc[0][mt][nt], Bl)
+                    WM_MM6(acc[1][mt][nt], Bc)
+                    WM_MM6(acc[2][mt][nt], Br)
+#undef WM_MM6
+                }
+            }
+        }
+        __syncthreads();
+        if (next < ntiles) write_tile(next);
+        __syncthreads();
+        tile = next;
+    }
+
+    float* out = a.partial + (size_t)blockIdx.x * (KW * 4096 + 64);
+    float* red = reinterpret_cast<float*>(smem_raw);          // KW*4096 floats = 48 KB <= LDS images (104 KB)
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int k = 0; k < KW; ++k)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int o = (k * 64 + mt * 32 + mfma_row(r, half)) * 64 + nt * 32 + l31;
+                            red[o] = (w == 0) ? acc[k][mt][nt][r] : red[o] + acc[k][mt][nt][r];
+                        }
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < KW * 4096; i += 256) out[i] = red[i];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const float v = half_wave_sum(bsum[i]);
+        if (l31 == 0) out[KW * 4096 + (tid >> 5) + 8 * i] = v;
+    }
+}
+
+template <int GPRO, int XPRO>
+int launch_wgrad64bf(const Wgrad64Args& a, int* grid_out, hipStream_t stream) {
+    constexpr size_t lds = (size_t)(3 * 64 * 136 + 3 * 64 * 152) * 2 + 6 * 64 * sizeof(float);
+    static bool attr_done = false;
+    auto kern = wgrad64bf_kernel<GPRO, XPRO>;
+    if (!attr_done) {
+        WM_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    const int ntiles = a.B * ((a.T + 127) / 128);
+    const int grid = ntiles < kNumCU ? ntiles : kNumCU;
+    *grid_out = grid;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, a);
+    WM_CHECK_LAUNCH();
+    return 0;
 }
 
 }  // namespace
@@ -598,6 +1048,46 @@ int wm_conv64(const float* x, const float* x2, const float* wp, const float* pa,
         if (pro == PRO_NONE && epi == EPI_NONE) return launch_conv64<7, 128, PRO_NONE, EPI_NONE, false>(a, stream);
     }
     return (int)hipErrorInvalidValue;
+}
+
+// bf16x6 build of the k3 convolution (fp32-grade results on the bf16 matrix cores); wpb from wm_pack_w64_bf.
+// Same pro / epi / stats contract as wm_conv64 with KW = 3.
+int wm_pack_w64_bf(const float* w, void* wpb, int mode, hipStream_t stream) {
+    if (mode < 0 || mode > 1) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(pack_w64_bf_kernel, dim3(48), dim3(256), 0, stream, w, reinterpret_cast<unsigned short*>(wpb), mode);
+    WM_CHECK_LAUNCH();
+    return 0;
+}
+
+int wm_conv64_bf(const float* x, const float* x2, const void* wpb, const float* pa, const float* pb, const float* pc,
+                 const float* bias, const float* e1, const float* ea, const float* eb, float* y, float* stats,
+                 int B, int T, int pro, int epi, hipStream_t stream) {
+    if (B <= 0 || T <= 0 || (T & 3)) return (int)hipErrorInvalidValue;
+    Conv64Args a{x, x2, reinterpret_cast<const float*>(wpb), pa, pb, pc, bias, e1, ea, eb, y, stats, B, T};
+    const bool st = stats != nullptr;
+    if (pro == PRO_NONE && epi == EPI_BIAS) return st ? launch_conv64bf<PRO_NONE, EPI_BIAS, true>(a, stream) : launch_conv64bf<PRO_NONE, EPI_BIAS, false>(a, stream);
+    if (pro == PRO_BNRELU && epi == EPI_BIAS) return st ? launch_conv64bf<PRO_BNRELU, EPI_BIAS, true>(a, stream) : launch_conv64bf<PRO_BNRELU, EPI_BIAS, false>(a, stream);
+    if (pro == PRO_BNBWD && epi == EPI_RELUMASK && st) return launch_conv64bf<PRO_BNBWD, EPI_RELUMASK, true>(a, stream);
+    if (pro == PRO_BNBWD && epi == EPI_ADD && !st) return launch_conv64bf<PRO_BNBWD, EPI_ADD, false>(a, stream);
+    if (pro == PRO_BNBWD && epi == EPI_NONE && !st) return launch_conv64bf<PRO_BNBWD, EPI_NONE, false>(a, stream);
+    return (int)hipErrorInvalidValue;
+}
+
+// bf16x6 build of the k3 weight gradient (same contract as wm_wgrad64 with KW = 3, layout 0)
+int wm_wgrad64_bf(const float* g, const float* g2, const float* ga, const float* gb, const float* gc,
+                  const float* x, const float* xa, const float* xb, float* partial, float* dw, float* dbias,
+                  int B, int T, int gpro, int xpro, int accumulate, hipStream_t stream) {
+    if (B <= 0 || T <= 0 || (T & 3)) return (int)hipErrorInvalidValue;
+    Wgrad64Args a{g, g2, ga, gb, gc, x, xa, xb, partial, B, T};
+    int grid = 0, rc = (int)hipErrorInvalidValue;
+    if (gpro == PRO_BNBWD && xpro == PRO_BNRELU) rc = launch_wgrad64bf<PRO_BNBWD, PRO_BNRELU>(a, &grid, stream);
+    else if (gpro == PRO_BNBWD && xpro == PRO_NONE) rc = launch_wgrad64bf<PRO_BNBWD, PRO_NONE>(a, &grid, stream);
+    if (rc) return rc;
+    const int n = 3 * 4096 + 64;
+    hipLaunchKernelGGL(wgrad64_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, (const float*)partial, grid, 3, 0, dw,
+                       dbias, accumulate);
+    WM_CHECK_LAUNCH();
+    return 0;
 }
 
 // Weight gradient of a 64->64 convolution.  partial: [256][KW*4096+64] scratch.

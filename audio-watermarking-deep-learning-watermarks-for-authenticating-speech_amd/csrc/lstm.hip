@@ -428,8 +428,9 @@ __global__ void lstm_wgrad_reduce_kernel(const float* __restrict__ partial, int 
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     constexpr int stride = 256 * 128 + 256;
     if (i >= stride) return;
-    float s = 0.f;
-    for (int p = 0; p < nparts; ++p) s += partial[(size_t)p * stride + i];
+    double sd = 0.0;
+    for (int p = 0; p < nparts; ++p) sd += (double)partial[(size_t)p * stride + i];
+    const float s = (float)sd;
     if (i < 256 * 128) {
         const int n = gate_row(i >> 7), j = i & 127;
         float* dst = (j < 64) ? dw_ih + n * 64 + j : dw_hh + n * 64 + (j - 64);

@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void stem_bwd_kernel(const float* __restrict__
     const int tilesPerClip = (T + NT - 1) / NT, ntiles = B * tilesPerClip;
     // reduction roles: thread -> (co = tid >> 2, jg = tid & 3) handles taps jg and jg + 4 (tap 7 == bias)
     const int rco = tid >> 2, rj = tid & 3;
-    float accA = 0.f, accB = 0.f;
+    double accA = 0.0, accB = 0.0;      // cross-tile accumulation in fp64: these sums cancel heavily (bias gradient)
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int b = tile / tilesPerClip, t0 = (tile % tilesPerClip) * NT;
         const float* gb = g + (size_t)b * 64 * T;
@@ -115,12 +115,12 @@ __global__ __launch_bounds__(256) void stem_bwd_kernel(const float* __restrict__
 #pragma unroll 8
                 for (int t = 0; t < NT; ++t) { const float gv = gp[t]; a0 = fmaf(gv, sA[t], a0); a1 += gv; }
             }
-            accA += a0; accB += a1;
+            accA += (double)a0; accB += (double)a1;
         }
     }
     float* out = partial + (size_t)blockIdx.x * 512;
-    out[rco * 8 + rj] = accA;
-    out[rco * 8 + rj + 4] = accB;
+    out[rco * 8 + rj] = (float)accA;
+    out[rco * 8 + rj + 4] = (float)accB;
 }
 
 // out[i] (+)= sum_p partial[p*stride + i],  i < count
@@ -128,16 +128,17 @@ __global__ void reduce_partials_kernel(const float* __restrict__ partial, int np
                                        float* __restrict__ out, int accumulate) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
-    float s = 0.f;
-    for (int p = 0; p < nparts; ++p) s += partial[(size_t)p * stride + i];
-    out[i] = accumulate ? out[i] + s : s;
+    double s = 0.0;
+    for (int p = 0; p < nparts; ++p) s += (double)partial[(size_t)p * stride + i];
+    out[i] = accumulate ? out[i] + (float)s : (float)s;
 }
 // stem partial [nparts][64][8] -> dw[64][7], db[64]
 __global__ void stem_reduce_kernel(const float* __restrict__ partial, int nparts, float* dw, float* db, int accumulate) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= 512) return;
-    float s = 0.f;
-    for (int p = 0; p < nparts; ++p) s += partial[(size_t)p * 512 + i];
+    double sd = 0.0;
+    for (int p = 0; p < nparts; ++p) sd += (double)partial[(size_t)p * 512 + i];
+    const float s = (float)sd;
     const int co = i >> 3, j = i & 7;
     float* dst = (j < 7) ? dw + co * 7 + j : db + co;
     *dst = accumulate ? *dst + s : s;

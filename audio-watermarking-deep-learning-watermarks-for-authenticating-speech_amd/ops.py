@@ -93,6 +93,37 @@ def _on_side(inputs, fn):
         fn()
 
 
+# ---------------------------------------------------------------------------------------------- conv arithmetic mode
+# k3 convolutions (forward + data gradient): native fp32 MFMA, or the bf16x6 split build (fp32-grade error on the
+# bf16 matrix cores, see csrc/conv64.hip).  WM_CONV_BF16X6=0/1 in the environment overrides the default.
+import os as _os
+_CONV = {"bf16x6": _os.environ.get("WM_CONV_BF16X6", "1") == "1"}
+
+
+def set_conv_bf16x6(on: bool):
+    _CONV["bf16x6"] = bool(on)
+
+
+def conv_bf16x6() -> bool:
+    return _CONV["bf16x6"]
+
+
+def pack_w64_bf(w: torch.Tensor, mode: int) -> torch.Tensor:
+    wpb = torch.empty(3 * 3 * 4096, dtype=torch.int16, device=w.device)
+    lib.wm_pack_w64_bf(_p(w), _p(wpb), mode, _stream())
+    return wpb
+
+
+def _conv3(x, x2, w, mode, pa, pb, pc, bias, e1, ea, eb, y, stats, B, T, pro, epi):
+    """one k3 64->64 convolution launch in the selected arithmetic mode (mode: 0 forward, 1 data gradient)"""
+    if _CONV["bf16x6"]:
+        lib.wm_conv64_bf(_p(x), _p(x2), _p(pack_w64_bf(w, mode)), _p(pa), _p(pb), _p(pc), _p(bias), _p(e1), _p(ea), _p(eb), _p(y),
+                         _p(stats), B, T, pro, epi, _stream())
+    else:
+        lib.wm_conv64(_p(x), _p(x2), _p(pack_w64(w, 3, mode)), _p(pa), _p(pb), _p(pc), _p(bias), _p(e1), _p(ea), _p(eb), _p(y),
+                      _p(stats), B, T, 3, pro, epi, _stream())
+
+
 def pack_w64(w: torch.Tensor, kw: int, mode: int) -> torch.Tensor:
     wp = _f32(kw * 4096, device=w.device)
     lib.wm_pack_w64(_p(w), _p(wp), kw, mode, _stream())
@@ -108,23 +139,22 @@ class ResBlockFn(torch.autograd.Function):
         x = _frames(x, "ResBlock input", 64)
         B, _, T = x.shape
         dev, st = x.device, _stream()
-        wp1, wp2 = pack_w64(w1, 3, 0), pack_w64(w2, 3, 0)
         y1, y2, out = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
         cst = _f32(8, 64, device=dev)       # sc1 sh1 mean1 is1 sc2 sh2 mean2 is2
         sc1, sh1, mu1, is1, sc2, sh2, mu2, is2 = cst.unbind(0)
         if training:
             stats = _f32(NCU * 128, device=dev)
-            lib.wm_conv64(_p(x), None, _p(wp1), None, None, None, _p(b1), None, None, None, _p(y1), _p(stats), B, T, 3, 0, 0, st)
+            _conv3(x, None, w1, 0, None, None, None, b1, None, None, None, y1, stats, B, T, 0, 0)
             lib.wm_bn_finalize(_p(stats), NCU, float(B * T), _p(g1), _p(be1), _p(rm1), _p(rv1), _p(nbt1), BN_MOMENTUM, BN_EPS,
                                _p(sc1), _p(sh1), _p(mu1), _p(is1), st)
-            lib.wm_conv64(_p(y1), None, _p(wp2), _p(sc1), _p(sh1), None, _p(b2), None, None, None, _p(y2), _p(stats), B, T, 3, 1, 0, st)
+            _conv3(y1, None, w2, 0, sc1, sh1, None, b2, None, None, None, y2, stats, B, T, 1, 0)
             lib.wm_bn_finalize(_p(stats), NCU, float(B * T), _p(g2), _p(be2), _p(rm2), _p(rv2), _p(nbt2), BN_MOMENTUM, BN_EPS,
                                _p(sc2), _p(sh2), _p(mu2), _p(is2), st)
         else:
             lib.wm_bn_eval_scale_shift(_p(g1), _p(be1), _p(rm1), _p(rv1), BN_EPS, _p(sc1), _p(sh1), st)
             lib.wm_bn_eval_scale_shift(_p(g2), _p(be2), _p(rm2), _p(rv2), BN_EPS, _p(sc2), _p(sh2), st)
-            lib.wm_conv64(_p(x), None, _p(wp1), None, None, None, _p(b1), None, None, None, _p(y1), None, B, T, 3, 0, 0, st)
-            lib.wm_conv64(_p(y1), None, _p(wp2), _p(sc1), _p(sh1), None, _p(b2), None, None, None, _p(y2), None, B, T, 3, 1, 0, st)
+            _conv3(x, None, w1, 0, None, None, None, b1, None, None, None, y1, None, B, T, 0, 0)
+            _conv3(y1, None, w2, 0, sc1, sh1, None, b2, None, None, None, y2, None, B, T, 1, 0)
             # saved (mean, invstd) for an eval-mode backward = running statistics
             mu1.copy_(rm1); is1.copy_(torch.rsqrt(rv1 + BN_EPS)); mu2.copy_(rm2); is2.copy_(torch.rsqrt(rv2 + BN_EPS))
         lib.wm_bn_add_relu(_p(x), _p(y2), _p(sc2), _p(sh2), _p(out), B, T, st)
@@ -145,38 +175,43 @@ class ResBlockFn(torch.autograd.Function):
         dz2 = torch.empty_like(x)
         part = _f32(max(B, 1) * 128, device=dev)
         lib.wm_relu_bwd_reduce(_p(g_out), _p(out), _p(y2), _p(dz2), _p(part), B, T, st)
-        k2 = _f32(3, 64, device=dev)
+        k2 = _f32(4, 64, device=dev)          # A, B (hi), B (lo), C  -- B is handed over as hi + lo words
         dg2, dbe2 = _f32(64, device=dev), _f32(64, device=dev)
-        lib.wm_bn_bwd_finalize(_p(part), B, n, _p(g2), _p(mu2), _p(is2), _p(k2[0]), _p(k2[1]), _p(k2[2]), _p(dg2), _p(dbe2), 0, ev, st)
+        lib.wm_bn_bwd_finalize(_p(part), B, n, _p(g2), _p(mu2), _p(is2), _p(k2[0]), _p(k2[1]), _p(k2[3]), _p(dg2), _p(dbe2), 0, ev, st)
         # conv2: data gradient (+ ReLU mask + BN1-backward reductions in the epilogue) and weight gradient
-        wp2d = pack_w64(w2, 3, 1)
         dz1 = torch.empty_like(x)
         stats = _f32(NCU * 128, device=dev)
-        lib.wm_conv64(_p(dz2), _p(y2), _p(wp2d), _p(k2[0]), _p(k2[1]), _p(k2[2]), None, _p(y1), _p(sc1), _p(sh1), _p(dz1), _p(stats),
-                      B, T, 3, 3, 1, st)
+        _conv3(dz2, y2, w2, 1, k2[0], k2[1], k2[3], None, y1, sc1, sh1, dz1, stats, B, T, 3, 1)
         gw1, gb1, gw2, gb2 = ctx.gdst
         side = all(g is not None for g in ctx.gdst)
 
         def wgrad2():
             wpart = _f32(2 * NCU * (3 * 4096 + 64), device=dev)
-            lib.wm_wgrad64(_p(dz2), _p(y2), _p(k2[0]), _p(k2[1]), _p(k2[2]), _p(y1), _p(sc1), _p(sh1), _p(wpart),
-                           _p(gw2 if side else dw2), _p(gb2 if side else db2), B, T, 3, 3, 1, 0, 1 if side else 0, _stream())
+            if _CONV["bf16x6"]:
+                lib.wm_wgrad64_bf(_p(dz2), _p(y2), _p(k2[0]), _p(k2[1]), _p(k2[3]), _p(y1), _p(sc1), _p(sh1), _p(wpart),
+                                  _p(gw2 if side else dw2), _p(gb2 if side else db2), B, T, 3, 1, 1 if side else 0, _stream())
+            else:
+                lib.wm_wgrad64(_p(dz2), _p(y2), _p(k2[0]), _p(k2[1]), _p(k2[3]), _p(y1), _p(sc1), _p(sh1), _p(wpart),
+                               _p(gw2 if side else dw2), _p(gb2 if side else db2), B, T, 3, 3, 1, 0, 1 if side else 0, _stream())
         dw2, db2 = (None, None) if side else (torch.empty_like(w2), _f32(64, device=dev))
         if side:
             _on_side((dz2, y2, k2, y1, cst), wgrad2)
         else:
             wgrad2()
-        k1 = _f32(3, 64, device=dev)
+        k1 = _f32(4, 64, device=dev)
         dg1, dbe1 = _f32(64, device=dev), _f32(64, device=dev)
-        lib.wm_bn_bwd_finalize(_p(stats), NCU, n, _p(g1), _p(mu1), _p(is1), _p(k1[0]), _p(k1[1]), _p(k1[2]), _p(dg1), _p(dbe1), 0, ev, st)
+        lib.wm_bn_bwd_finalize(_p(stats), NCU, n, _p(g1), _p(mu1), _p(is1), _p(k1[0]), _p(k1[1]), _p(k1[3]), _p(dg1), _p(dbe1), 0, ev, st)
         # conv1: data gradient + residual path, weight gradient
-        wp1d = pack_w64(w1, 3, 1)
         dx = torch.empty_like(x)
-        lib.wm_conv64(_p(dz1), _p(y1), _p(wp1d), _p(k1[0]), _p(k1[1]), _p(k1[2]), None, _p(dz2), None, None, _p(dx), None, B, T, 3, 3, 2, st)
+        _conv3(dz1, y1, w1, 1, k1[0], k1[1], k1[3], None, dz2, None, None, dx, None, B, T, 3, 2)
         def wgrad1():
             wpart = _f32(2 * NCU * (3 * 4096 + 64), device=dev)
-            lib.wm_wgrad64(_p(dz1), _p(y1), _p(k1[0]), _p(k1[1]), _p(k1[2]), _p(x), None, None, _p(wpart),
-                           _p(gw1 if side else dw1), _p(gb1 if side else db1), B, T, 3, 3, 0, 0, 1 if side else 0, _stream())
+            if _CONV["bf16x6"]:
+                lib.wm_wgrad64_bf(_p(dz1), _p(y1), _p(k1[0]), _p(k1[1]), _p(k1[3]), _p(x), None, None, _p(wpart),
+                                  _p(gw1 if side else dw1), _p(gb1 if side else db1), B, T, 3, 0, 1 if side else 0, _stream())
+            else:
+                lib.wm_wgrad64(_p(dz1), _p(y1), _p(k1[0]), _p(k1[1]), _p(k1[3]), _p(x), None, None, _p(wpart),
+                               _p(gw1 if side else dw1), _p(gb1 if side else db1), B, T, 3, 3, 0, 0, 1 if side else 0, _stream())
         dw1, db1 = (None, None) if side else (torch.empty_like(w1), _f32(64, device=dev))
         if side:
             _on_side((dz1, y1, k1, x), wgrad1)

@@ -149,8 +149,14 @@ def main():
         sync = (lambda: wmd.allreduce_flat_gradient(opt.grad)) if world > 1 else None
     s, msg = synthetic_batch(args.batch, rank, dev)
 
-    # dominant kernel: the 64->64 k3 forward convolution of the ResBlocks (wm_conv64, KW=3, epi=bias)
-    timer = LaunchTimer(awm_amd.lib, "wm_conv64", lambda a: a[14] == 3 and a[16] == 0)
+    # dominant kernel: the 64->64 k3 forward convolution of the ResBlocks (epi = bias): wm_conv64_bf (bf16x6 split build,
+    # the default) or wm_conv64 with KW = 3 (native fp32 MFMA build, WM_CONV_BF16X6=0)
+    from awm_amd import ops as _ops
+    bf_mode = _ops.conv_bf16x6()
+    if bf_mode:
+        timer = LaunchTimer(awm_amd.lib, "wm_conv64_bf", lambda a: a[15] == 0)
+    else:
+        timer = LaunchTimer(awm_amd.lib, "wm_conv64", lambda a: a[14] == 3 and a[16] == 0)
 
     def step():
         return step_fn(G, D, opt, s, msg, grad_sync=sync)
@@ -193,7 +199,8 @@ def main():
         try:
             if args.batch == 256:
                 pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_fetch_write_b256.json")))["kernels"]
-                ks = [v["hbm_bytes_per_launch_corrected"] for k, v in pm.items() if k.startswith("conv64_kernel<3, 256")]
+                ks = [v["hbm_bytes_per_launch_corrected"] for k, v in pm.items()
+                      if k.startswith("conv64bf_kernel<0, 0" if bf_mode else "conv64_kernel<3, 256") or k.startswith("conv64bf_kernel<1, 0" if bf_mode else "conv64_kernel<3, 256")]
                 traffic = sum(ks) / len(ks) if ks else None
         except Exception:
             traffic = None
@@ -202,7 +209,11 @@ def main():
             ach = flops_launch / (k_ms * 1e-3) / 1e12
             roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
-                        "kernel": "conv64_kernel<KW=3> forward (wm_conv64: Conv1d(64,64,3)+bias, BN+ReLU fused on load, BN sums in epilogue)",
+                                "kernel": ("conv64bf_kernel forward (wm_conv64_bf: Conv1d(64,64,3)+bias as bf16x6 split products on the bf16 "
+                                   "matrix cores, fp32 accumulate, fp32-grade error; BN+ReLU fused on load, BN sums in epilogue)") if bf_mode else
+                                  "conv64_kernel<KW=3> forward (wm_conv64: native fp32 MFMA; BN+ReLU fused on load, BN sums in epilogue)",
+                        "bf16_mfma_flops_per_launch": (6.0 * flops_launch) if bf_mode else None,
+                        "frac_of_bf16_dense_peak_2500TF": round(6.0 * ach / 2500.0, 4) if bf_mode else None,
                         "avg_launch_ms": round(k_ms, 4), "launches_timed": len(timer.events),
                         "algorithmic_flops_per_launch": flops_launch, "algorithmic_bytes_per_launch": bytes_launch,
                         "hbm_achieved_GBs": round(bytes_launch / (k_ms * 1e-3) / 1e9, 1),
@@ -219,6 +230,7 @@ def main():
                 "config": {"workload": workload,
                            "batch_per_gpu": args.batch, "global_batch": args.batch * world, "clip_len": T,
                            "optimizer": "torch.optim.Adam" if args.torch_adam else "fused flat Adam (wm_adam_step)",
+                           "conv_arithmetic": "k3 convs fwd+dgrad: bf16x6 split on bf16 MFMA, fp32 accumulate (2.7e-7 vs fp64; native fp32 MFMA 2.5e-7)" if (args.model == "main16" and bf_mode) else "native fp32 MFMA",
                            "parallelism": f"dp{world}" if world > 1 else "single"},
                 "loss": round(total_loss, 6), "roofline": roofline}
         if world == 1 and not args.no_cpu_baseline and args.model == "main16":

@@ -34,13 +34,27 @@ int wm_pack_w64(const float* w, float* wp, int KW, int mode, wm_stream_t stream)
 
 /* y = conv_same(pro(x)) then epi.
  *   pro: 0 x | 1 relu(x*pa[c]+pb[c]) (BatchNorm+ReLU folded into the load, py/main16.py:117-118)
- *        | 2 x + pa[b*64+c] (message embedding add, py/main16.py:158-159) | 3 pa[c]*x + pb[c] + pc[c]*x2 (BN backward)
+ *        | 2 x + pa[b*64+c] (message embedding add, py/main16.py:158-159) | 3 pa[c]*x + (pb[c] + pb[64+c]) + pc[c]*x2 (BN backward; pb is [2][64]: offset as hi + lo words)
  *   epi: 0 + bias[c] | 1 keep where e1*ea[c]+eb[c] > 0 (ReLU backward) | 2 + e1 (residual gradient) | 3 none
  *   stats (NULL or [256][2][64]): per-workgroup partial sums for BatchNorm (epi 0: sum y, sum y^2;
  *   epi 1: sum v, sum v*e1).  Supported (KW,pro,epi): (3,{0,1},0) (3,3,{1,2,3}) (7,{0,2},0) (7,0,3).          */
 int wm_conv64(const float* x, const float* x2, const float* wp, const float* pa, const float* pb, const float* pc,
               const float* bias, const float* e1, const float* ea, const float* eb, float* y, float* stats,
               int B, int T, int KW, int pro, int epi, wm_stream_t stream);
+
+/* bf16x6 build of the k3 convolution: every fp32 operand is split into three bf16 pieces in LDS and the six piece
+ * products of weight >= 2^-16 are accumulated in fp32 on the bf16 matrix cores (fp32-grade error, 6/16 of the fp32 MFMA
+ * time).  Same pro / epi / stats contract as wm_conv64 with KW = 3; wpb [3][3][64][64] uint16 from wm_pack_w64_bf
+ * (mode 0 Conv1d fwd | 1 Conv1d dgrad). */
+int wm_pack_w64_bf(const float* w, void* wpb, int mode, wm_stream_t stream);
+int wm_conv64_bf(const float* x, const float* x2, const void* wpb, const float* pa, const float* pb, const float* pc,
+                 const float* bias, const float* e1, const float* ea, const float* eb, float* y, float* stats,
+                 int B, int T, int pro, int epi, wm_stream_t stream);
+
+/* bf16x6 build of the k3 Conv1d weight gradient (contract of wm_wgrad64 with KW = 3, layout 0) */
+int wm_wgrad64_bf(const float* g, const float* g2, const float* ga, const float* gb, const float* gc,
+                  const float* x, const float* xa, const float* xb, float* partial, float* dw, float* dbias,
+                  int B, int T, int gpro, int xpro, int accumulate, wm_stream_t stream);
 
 /* dW (+)= sum_{b,t} gpro(g)[out,t] * xpro(x)[in,t+tap-KW/2]; dbias (+)= sum gpro(g).  partial: [512][KW*4096+64].
  *   gpro 0|3, xpro 0|1|2 as above; layout 0: Conv1d weight [out][in][KW], 1: ConvTranspose1d weight [in][out][KW]. */
@@ -59,6 +73,7 @@ int wm_bn_add_relu(const float* x, const float* y2, const float* scale, const fl
                    wm_stream_t stream);
 int wm_relu_bwd_reduce(const float* g, const float* out, const float* y2, float* dz, float* partial, int B, int T,
                        wm_stream_t stream);
+/* A, Cc: [64]; Bc: [2][64] (hi, lo words of the offset, see wm_conv64 pro 3) */
 int wm_bn_bwd_finalize(const float* partials, int nparts, double count, const float* gamma, const float* save_mean,
                        const float* save_invstd, float* A, float* Bc, float* Cc, float* dgamma, float* dbeta,
                        int accumulate, int eval_mode, wm_stream_t stream);

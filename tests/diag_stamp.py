@@ -6,7 +6,7 @@ L = ctypes.CDLL(so)
 dev = torch.device("cuda:0"); B, T = 256, 16000
 x = torch.randn(B, 64, T, device=dev); y = torch.empty_like(x); x2 = torch.randn(B, 64, T, device=dev); x3 = torch.randn(B, 64, T, device=dev)
 w = torch.randn(64, 64, 3, device=dev) * 0.05; wp = torch.empty(3 * 4096, device=dev); bias = torch.randn(64, device=dev)
-c = [torch.rand(64, device=dev) for _ in range(5)]
+c = [torch.rand(128, device=dev) for _ in range(5)]
 stats = torch.empty(256 * 128, device=dev)
 buf = torch.zeros(256 * 4 * 6, dtype=torch.int64, device=dev)
 vp = ctypes.c_void_p

@@ -37,7 +37,7 @@ def test_header_types_are_plain_c():
         assert args[-1] == ("wm_stream_t", "stream"), name
         for ctype, _ in args:
             base = ctype.replace("const ", "").replace("*", "").strip()
-            assert base in ("float", "int", "double", "long long", "wm_stream_t"), (name, ctype)
+            assert base in ("float", "int", "double", "long long", "void", "wm_stream_t"), (name, ctype)
 
 
 def test_module_layout_and_init_match_reference(golden):
