@@ -47,6 +47,9 @@ int wm_conv64(const float* x, const float* x2, const float* wp, const float* pa,
  * time).  Same pro / epi / stats contract as wm_conv64 with KW = 3; wpb [3][3][64][64] uint16 from wm_pack_w64_bf
  * (mode 0 Conv1d fwd | 1 Conv1d dgrad). */
 int wm_pack_w64_bf(const float* w, void* wpb, int mode, wm_stream_t stream);
+/* schedule of wm_conv64_bf (process-wide knob for experiments; default 0): 0 one wave per SIMD, 128-column tiles |
+ * 1 two groups of four waves half a period apart, 64-column tiles (the bf16 MFMA runs beside the partner's VALU work) */
+int wm_set_conv_bf_schedule(int schedule, wm_stream_t stream);
 int wm_conv64_bf(const float* x, const float* x2, const void* wpb, const float* pa, const float* pb, const float* pc,
                  const float* bias, const float* e1, const float* ea, const float* eb, float* y, float* stats,
                  int B, int T, int pro, int epi, wm_stream_t stream);

@@ -12,6 +12,19 @@ buf = torch.zeros(256 * 4 * 6, dtype=torch.int64, device=dev)
 vp = ctypes.c_void_p
 L.wm_debug_set_stamp_buffer(vp(buf.data_ptr()))
 L.wm_pack_w64(vp(w.data_ptr()), vp(wp.data_ptr()), 3, 0, None)
+wpb = torch.empty(3 * 3 * 4096, dtype=torch.int16, device=dev)
+L.wm_pack_w64_bf(vp(w.data_ptr()), vp(wpb.data_ptr()), 0, None)
+def run_bf(name, pro, epi, st):
+    args = [vp(x.data_ptr()), vp(x2.data_ptr()) if pro == 3 else None, vp(wpb.data_ptr()),
+            vp(c[0].data_ptr()), vp(c[1].data_ptr()), vp(c[2].data_ptr()), vp(bias.data_ptr()),
+            vp(x3.data_ptr()) if epi in (1, 2) else None, vp(c[3].data_ptr()), vp(c[4].data_ptr()), vp(y.data_ptr()),
+            vp(stats.data_ptr()) if st else None, B, T, pro, epi, None]
+    for _ in range(2):
+        buf.zero_(); rc = L.wm_conv64_bf(*args); torch.cuda.synchronize()
+    assert rc == 0, rc
+    d = buf.view(256, 4, 6).double().mean(dim=(0, 1))
+    names = ["load-issue+e1", "mfma", "epilogue", "bar1", "lds-write", "bar2"]
+    print(f"bf {name:25s} " + "  ".join(f"{n} {v:9.0f}" for n, v in zip(names, d)) + f"   total {d.sum():9.0f}")
 def run(name, pro, epi, st):
     args = [vp(x.data_ptr()), vp(x2.data_ptr()) if pro == 3 else None, vp(wp.data_ptr()),
             vp(c[0].data_ptr()), vp(c[1].data_ptr()), vp(c[2].data_ptr()), vp(bias.data_ptr()),
@@ -29,3 +42,8 @@ run("fwd bnrelu/bias +stats", 1, 0, True)
 run("dgrad bnbwd/relumask +stats", 3, 1, True)
 run("dgrad bnbwd/add", 3, 2, False)
 run("dgrad bnbwd/none", 3, 3, False)
+run_bf("fwd none/bias", 0, 0, False)
+run_bf("fwd none/bias +stats", 0, 0, True)
+run_bf("fwd bnrelu/bias +stats", 1, 0, True)
+run_bf("dgrad bnbwd/relumask +stats", 3, 1, True)
+run_bf("dgrad bnbwd/add", 3, 2, False)
