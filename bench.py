@@ -107,6 +107,9 @@ def main():
     ap.add_argument("--model", choices=["main16", "main14b_2"], default="main16",
                     help="main16: BASELINE configs[2]/[3] (default, the headline metric); main14b_2: configs[4] "
                          "(deep-residual variant, hidden_dim=256, default --batch 128)")
+    ap.add_argument("--mode", choices=["train", "fwd"], default="train",
+                    help="train: fwd+bwd+Adam (the BASELINE metric, default); fwd: eval-mode forward only "
+                         "(BASELINE configs[1]: use --batch 64) -- reported with its own metric name")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--torch-adam", action="store_true", help="use torch.optim.Adam instead of the fused flat Adam")
     args = ap.parse_args()
@@ -161,6 +164,14 @@ def main():
     def step():
         return step_fn(G, D, opt, s, msg, grad_sync=sync)
 
+    if args.mode == "fwd":
+        if args.model != "main16":
+            raise SystemExit("--mode fwd is wired for main16")
+        G.eval(); D.eval()
+
+        def step():                                     # noqa: F811  (evaluate_model's forward, py/main16.py:383-403)
+            return awm_amd.eval_forward(G, D, s, msg)
+
     for _ in range(args.warmup):
         step()
 
@@ -182,8 +193,8 @@ def main():
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-    total_loss = float(out["total"])
-    assert total_loss == total_loss, "NaN loss"
+    total_loss = float(out["total"]) if args.mode == "train" else float(out["delta_rms"].mean())
+    assert total_loss == total_loss, "NaN"
 
     if rank == 0:
         ms_step = 1e3 * dt / args.steps
@@ -224,7 +235,10 @@ def main():
                     f"1-s @ 16 kHz, message_bits=16 (BASELINE configs[{2 if world == 1 else 3}])") if args.model == "main16" else \
                    (f"main14b_2 deep-residual train step (hidden_dim=256, 2-layer LSTM): Generator+Detector+5 losses fwd-bwd + Adam, "
                     f"B={args.batch} clips/GPU x {world} GPU (BASELINE configs[4])")
-        line = {"metric": "1-s@16kHz clips/sec (gen+det+loss fwd-bwd)", "value": round(value, 2), "unit": "clips/s",
+        if args.mode == "fwd":
+            workload = (f"main16 eval-mode forward only (Generator -> fir/clamp/rms -> Detector on [watermarked; clean] + evaluate_model "
+                        f"reductions), B={args.batch} clips/GPU x {world} GPU (BASELINE configs[1])")
+        line = {"metric": "1-s@16kHz clips/sec (gen+det+loss fwd-bwd)" if args.mode == "train" else "1-s@16kHz clips/sec (gen+det forward only, eval mode)", "value": round(value, 2), "unit": "clips/s",
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 3),
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                 "config": {"workload": workload,
@@ -233,7 +247,7 @@ def main():
                            "conv_arithmetic": "k3 convs fwd+dgrad: bf16x6 split on bf16 MFMA, fp32 accumulate (2.7e-7 vs fp64; native fp32 MFMA 2.5e-7)" if (args.model == "main16" and bf_mode) else "native fp32 MFMA",
                            "parallelism": f"dp{world}" if world > 1 else "single"},
                 "loss": round(total_loss, 6), "roofline": roofline}
-        if world == 1 and not args.no_cpu_baseline and args.model == "main16":
+        if world == 1 and not args.no_cpu_baseline and args.model == "main16" and args.mode == "train":
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)
     if world > 1:
