@@ -580,6 +580,9 @@ __device__ __forceinline__ void split3_pair(float a, float b, unsigned& p0, unsi
     p2 = __builtin_bit_cast(unsigned, l);
 }
 
+#ifndef WM_LOADPOS
+#define WM_LOADPOS 1
+#endif
 template <int PRO, int EPI, bool STATS>
 __global__ __launch_bounds__(256) void conv64bf_kernel(Conv64Args a) {
     constexpr int KW = 3, PAD = 1, NT = 128, ROWS = NT + 2, PITCH = 72, NP = 3;
@@ -692,17 +695,23 @@ __global__ __launch_bounds__(256) void conv64bf_kernel(Conv64Args a) {
     while (tile < ntiles) {
         STAMP(ts0);
         const int next = tile + gridDim.x;
-        if (next < ntiles) load_tile(next);
         const int b = tile / tilesPerClip, t0 = (tile - b * tilesPerClip) * NT;
         const int tcol = t0 + wave * 32 + l31;
         float e1r[E1 ? 32 : 1];
-        if (E1) {
-            const float* eb1 = a.e1 + (size_t)b * 64 * T + min(tcol, T - 1);
+        // The global loads of the next tile (and of this tile's epilogue operand) are issued LOADPOS taps into the
+        // matrix phase: issued at the top they queue behind the previous tile's output stores and the wave stalls
+        // at issue until those drain, with the matrix cores idle.
+        auto issue_loads = [&]() {
+            if (next < ntiles) load_tile(next);
+            if (E1) {
+                const float* eb1 = a.e1 + (size_t)b * 64 * T + min(tcol, T - 1);
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
+                for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) e1r[mt * 16 + r] = eb1[(size_t)(mt * 32 + mfma_row(r, half)) * T];
-        }
+                    for (int r = 0; r < 16; ++r) e1r[mt * 16 + r] = eb1[(size_t)(mt * 32 + mfma_row(r, half)) * T];
+            }
+        };
+        if (WM_LOADPOS == 0) issue_loads();
         STAMP(ts1);
         f32x16 acc[2];
 #pragma unroll
@@ -713,6 +722,7 @@ __global__ __launch_bounds__(256) void conv64bf_kernel(Conv64Args a) {
         const unsigned short* xbase = Xb + (wave * 32 + l31) * PITCH + 8 * half;
 #pragma unroll 1
         for (int tap = 0; tap < KW; ++tap) {
+            if (WM_LOADPOS > 0 && tap == WM_LOADPOS) issue_loads();
 #pragma unroll
             for (int ch = 0; ch < 4; ++ch) {
                 bf16x8 A[2][NP], Bf[NP];
@@ -796,6 +806,322 @@ int launch_conv64bf(const Conv64Args& a, hipStream_t stream) {
     constexpr size_t lds = (size_t)(3 * 3 * 64 * 72 + 3 * 130 * 72) * 2 + 6 * 64 * sizeof(float);
     static bool attr_done = false;
     auto kern = conv64bf_kernel<PRO, EPI, STATS>;
+    if (!attr_done) {
+        WM_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    const int ntiles = a.B * ((a.T + 127) / 128);
+    const int grid = ntiles < kNumCU ? ntiles : kNumCU;
+    if (STATS && grid < kNumCU) WM_TRY(hipMemsetAsync(a.stats, 0, sizeof(float) * 128 * kNumCU, stream));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, a);
+    WM_CHECK_LAUNCH();
+    return 0;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// bf16x6 convolution, register-resident weights and an interleaved pipeline ("bf3").
+// conv64bf_kernel above runs its phases back to back on one wave per SIMD: matrix phase, epilogue, barrier, split +
+// LDS write, barrier -- the matrix cores idle through every VALU phase (measured: 5.6 K of 14 K cycles per tile).
+// Here wave (mt, nh) keeps the weight fragments of its 32 output rows in registers for the whole kernel
+// (12 k-steps x 3 pieces x 4 VGPRs = 144 of the 512 a single resident wave may use), so LDS only carries the input
+// image -- small enough (2 x 55 KB) to double-buffer.  While the matrix cores work on tile i out of image A, the
+// same instruction stream, a few VALU/DS instructions after every MFMA, splits tile i+1 into image B and then
+// issues the global loads of tile i+2: one LDS-only barrier per tile, output stores stay in flight across it.
+// ---------------------------------------------------------------------------------------------
+#ifndef WM_LOAD_H
+#define WM_LOAD_H 17
+#endif
+#ifndef WM_TILE_CONTIG
+#define WM_TILE_CONTIG 0
+#endif
+#ifndef WM_NT_STORE
+#define WM_NT_STORE 0
+#endif
+__device__ __forceinline__ void lds_barrier() {          // s_barrier without draining vmcnt (global stores/prefetches stay in flight)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+template <int PRO, int EPI, bool STATS>
+__global__ __launch_bounds__(256) void conv64bf3_kernel(Conv64Args a) {
+    constexpr int KW = 3, NT = 128, ROWS = NT + 2, PITCH = 72, NP = 3, NC = 4;
+    constexpr int XBUF = NP * ROWS * PITCH;               // bf16 elements per input image
+    constexpr bool TWO = (PRO == PRO_BNBWD);
+    constexpr bool E1 = (EPI == EPI_RELUMASK || EPI == EPI_ADD);
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    unsigned short* Xb0 = reinterpret_cast<unsigned short*>(smem_raw);             // 2 x [NP][ROWS][PITCH]
+    float* Cs = reinterpret_cast<float*>(Xb0 + 2 * XBUF);                           // [6][64]
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform values stay in SGPRs (scalar address math)
+    const int mt = wave & 1, nh = wave >> 1;
+    const int T = a.T;                             // T % 128 == 0 (checked by the launcher): no partial tiles
+    const int tilesPerClip = (T + NT - 1) / NT, ntiles = a.B * tilesPerClip;
+
+    // ---- resident weight fragments: packed image [NP][KW][64 out][64 in] bf16
+    bf16x8 Wr[12][NP];
+    {
+        const uint4* wg = reinterpret_cast<const uint4*>(a.wp);
+#pragma unroll
+        for (int s = 0; s < 12; ++s)
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                const int e = ((p * KW + (s >> 2)) * 64 + 32 * mt + l31) * 64 + 16 * (s & 3) + 8 * half;
+                Wr[s][p] = __builtin_bit_cast(bf16x8, wg[e >> 3]);
+            }
+    }
+    // ---- staging map (fixed per thread): channel pair cp = 8*wave + (lane & 7), time quads q = 8*i + (lane >> 3)
+    const int cp = wave * 8 + (lane & 7), c0 = 2 * cp, q0 = lane >> 3;
+    const int hc = (tid & 127) >> 1, hh = tid & 1;
+    float4 sa[NC], sb[NC], sa2[TWO ? NC : 1], sb2[TWO ? NC : 1];
+    float hl, hl2 = 0.f;
+    // global -> register staging of one tile, in five pieces (4 combos + halo) so that the main loop can issue them
+    // a few at a time: a 32-KB burst per CU backs up the memory pipeline and blocks the wave at issue for ~2.5 K cycles
+    auto load_combo = [&](int tile, int i) {
+        const int b = tile / tilesPerClip, t0 = (tile - b * tilesPerClip) * NT;
+        const size_t o = ((size_t)b * 64 + c0) * T + t0 + 4 * (q0 + 8 * i);
+        sa[i] = *reinterpret_cast<const float4*>(a.x + o);
+        sb[i] = *reinterpret_cast<const float4*>(a.x + o + T);
+        if (TWO) { sa2[i] = *reinterpret_cast<const float4*>(a.x2 + o); sb2[i] = *reinterpret_cast<const float4*>(a.x2 + o + T); }
+    };
+    auto load_halo = [&](int tile) {              // branch-free: clamped address, masked when written to LDS
+        const int b = tile / tilesPerClip, t0 = (tile - b * tilesPerClip) * NT;
+        const int ht = min(max(hh ? t0 + NT : t0 - 1, 0), T - 1);
+        hl = a.x[((size_t)b * 64 + hc) * T + ht];
+        if (TWO) hl2 = a.x2[((size_t)b * 64 + hc) * T + ht];
+    };
+    auto load_tile = [&](int tile) {
+#pragma unroll
+        for (int i = 0; i < NC; ++i) load_combo(tile, i);
+        load_halo(tile);
+    };
+
+#if WM_TILE_CONTIG
+    const int chunk = (ntiles + (int)gridDim.x - 1) / (int)gridDim.x, tstep = 1;
+    int tile = blockIdx.x * chunk;
+    const int tend = min(tile + chunk, ntiles);
+#else
+    const int tstep = gridDim.x, tend = ntiles;
+    int tile = blockIdx.x;                        // grid <= ntiles
+#endif
+    load_tile(min(tile, ntiles - 1));
+    if (tid < 64) {
+        Cs[tid] = (PRO == PRO_BNRELU || PRO == PRO_BNBWD) ? a.pa[tid] : 0.f;
+        Cs[64 + tid] = (PRO == PRO_BNRELU || PRO == PRO_BNBWD) ? a.pb[tid] : 0.f;
+        Cs[128 + tid] = (PRO == PRO_BNBWD) ? a.pc[tid] : 0.f;
+        Cs[192 + tid] = (PRO == PRO_BNBWD) ? a.pb[64 + tid] : ((EPI == EPI_BIAS && a.bias) ? a.bias[tid] : 0.f);
+        Cs[256 + tid] = (EPI == EPI_RELUMASK) ? a.ea[tid] : 0.f;
+        Cs[320 + tid] = (EPI == EPI_RELUMASK) ? a.eb[tid] : 0.f;
+    }
+    __syncthreads();
+    // per-thread prologue constants (the staging channels never change)
+    const float ka0 = Cs[c0], ka1 = Cs[c0 + 1], kb0 = Cs[64 + c0], kb1 = Cs[64 + c0 + 1];
+    const float kc0 = Cs[128 + c0], kc1 = Cs[128 + c0 + 1], kl0 = TWO ? Cs[192 + c0] : 0.f, kl1 = TWO ? Cs[192 + c0 + 1] : 0.f;
+    const float ha = Cs[hc], hb = Cs[64 + hc], hcc = Cs[128 + hc], hlo = TWO ? Cs[192 + hc] : 0.f;
+
+    // one (combo i, element e) unit of the split: two channels x one time step -> 3 dwords
+    auto split_unit = [&](unsigned* X32, int t0, int i, int e) {
+        const float4 fa = sa[i], fb = sb[i];
+        float va = (e == 0) ? fa.x : (e == 1) ? fa.y : (e == 2) ? fa.z : fa.w;
+        float vb = (e == 0) ? fb.x : (e == 1) ? fb.y : (e == 2) ? fb.z : fb.w;
+        if (PRO != PRO_NONE) {
+            float wa = 0.f, wb = 0.f;
+            if (TWO) {
+                const float4 ga = sa2[i], gb = sb2[i];
+                wa = (e == 0) ? ga.x : (e == 1) ? ga.y : (e == 2) ? ga.z : ga.w;
+                wb = (e == 0) ? gb.x : (e == 1) ? gb.y : (e == 2) ? gb.z : gb.w;
+            }
+            va = pro_apply<PRO>(va, wa, ka0, kb0, kc0, kl0);
+            vb = pro_apply<PRO>(vb, wb, ka1, kb1, kc1, kl1);
+        }
+        unsigned p0, p1, p2;
+        split3_pair(va, vb, p0, p1, p2);
+        const int o = (1 + 4 * (q0 + 8 * i) + e) * (PITCH / 2) + cp;
+        X32[o] = p0; X32[(ROWS * PITCH >> 1) + o] = p1; X32[2 * (ROWS * PITCH >> 1) + o] = p2;
+    };
+    auto split_halo = [&](unsigned short* X, int t0) {
+        {                                             // threads 128..255 repeat the writes of 0..127 (no branch)
+            const int t = hh ? t0 + NT : t0 - 1;
+            float v = hl;
+            if (PRO != PRO_NONE) v = pro_apply<PRO>(v, hl2, ha, hb, hcc, hlo);
+            if (t < 0 || t >= T) v = 0.f;
+            unsigned p0, p1, p2;
+            split3_pair(v, 0.f, p0, p1, p2);
+            const int o = (hh ? NT + 1 : 0) * PITCH + hc;
+            X[o] = (unsigned short)p0; X[ROWS * PITCH + o] = (unsigned short)p1; X[2 * ROWS * PITCH + o] = (unsigned short)p2;
+        }
+    };
+    {
+        const int t0 = (min(tile, ntiles - 1) % tilesPerClip) * NT;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) split_unit(reinterpret_cast<unsigned*>(Xb0), t0, u >> 2, u & 3);
+        split_halo(Xb0, t0);
+    }
+    load_tile(min(tile + tstep, ntiles - 1));
+    __syncthreads();
+    // nothing pending on entry: the loop's vmcnt waits are then derived from its own (steady-state) issue order only
+    __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0)
+
+    float s1[STATS ? 16 : 1], s2[STATS ? 16 : 1];
+    if (STATS) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+    }
+    int buf = 0;
+#ifdef WM_STAMP
+    unsigned long long tm[6] = {0, 0, 0, 0, 0, 0};
+#endif
+    // The epilogue of a tile is deferred into the matrix phase of the NEXT tile (accp = its accumulators): the
+    // output stores trickle out between MFMAs instead of arriving as one 8-MB burst from all 256 CUs at once.
+    f32x16 accp[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accp[nt][r] = 0.f;
+    // "previous tile" of the first iteration = the first tile itself with pflag = 0: its zero accumulators are
+    // stored (and overwritten one iteration later by the same lanes, in program order) and add nothing to the sums.
+    int pb_ = min(tile, ntiles - 1) / tilesPerClip, pt0 = (min(tile, ntiles - 1) % tilesPerClip) * NT;
+    float pflag = 0.f;
+    float e1r[E1 ? 32 : 1];
+    const int loff = 4 * half * T + l31;            // per-lane part of every output / e1 address (fits 32 bits: < 8 T)
+    // scalar part: row (r&3) + 8 (r>>2) of this wave's 32 channels, column block nt
+    auto sidx = [&](int nt, int r) { return ((size_t)pb_ * 64 + 32 * mt + (r & 3) + 8 * (r >> 2)) * T + pt0 + 64 * nh + 32 * nt; };
+    if (E1) {
+#pragma unroll
+        for (int j = 0; j < 32; ++j) e1r[j] = 0.f;
+    }
+    // epilogue of value idx = nt * 16 + r of the previous tile; cb/ct0 = the tile being computed now, whose epilogue
+    // operand replaces the consumed one in the same register (it is needed one full iteration from now)
+    auto epi_value = [&](int idx, int cb, int ct0) {
+        const int nt = idx >> 4, r = idx & 15;
+        const int co = 32 * mt + mfma_row(r, half);
+        float v = accp[nt][r];
+        float q = 0.f;
+        if (EPI == EPI_BIAS) v += Cs[192 + co];
+        if (EPI == EPI_RELUMASK) { q = e1r[idx]; v = (fmaf(q, Cs[256 + co], Cs[320 + co]) > 0.f) ? v : 0.f; }
+        if (EPI == EPI_ADD) v += e1r[idx];
+#ifndef WM_X_NOSTORE
+        (a.y + sidx(nt, r))[loff] = v;
+#else
+        if (v == 123.456f) (a.y + sidx(nt, r))[loff] = v;
+#endif
+        if (STATS) { s1[r] = fmaf(pflag, v, s1[r]); s2[r] = fmaf(pflag * v, (EPI == EPI_RELUMASK) ? q : v, s2[r]); }
+        if (E1 && cb >= 0)
+            e1r[idx] = (a.e1 + ((size_t)cb * 64 + 32 * mt + (r & 3) + 8 * (r >> 2)) * T + ct0 + 64 * nh + 32 * nt)[loff];
+    };
+    while (tile < tend) {
+        STAMP(ts0);
+        // tiles past the end are clamped: their (valid) data lands in the image nobody reads again
+        const int next = min(tile + tstep, ntiles - 1), next2 = min(tile + 2 * tstep, ntiles - 1);
+        const int b = tile / tilesPerClip, t0 = (tile - b * tilesPerClip) * NT;
+        const int nt0 = (next % tilesPerClip) * NT;
+        const unsigned short* xcur = Xb0 + buf * XBUF;
+        unsigned short* xnxt = Xb0 + (buf ^ 1) * XBUF;
+        f32x16 acc[2];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+        const unsigned short* xrow = xcur + (64 * nh + l31) * PITCH + 8 * half;
+        bf16x8 Bq[2][NP];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) Bq[0][p] = *reinterpret_cast<const bf16x8*>(xrow + p * ROWS * PITCH);
+#pragma unroll
+        for (int h = 0; h < 24; ++h) {
+            const int s = h >> 1, nt = h & 1;
+            if (h + 1 < 24) {
+                const int s1_ = (h + 1) >> 1, n1 = (h + 1) & 1;
+#pragma unroll
+                for (int p = 0; p < NP; ++p)
+                    Bq[(h + 1) & 1][p] = *reinterpret_cast<const bf16x8*>(xrow + (p * ROWS + 32 * n1 + (s1_ >> 2)) * PITCH + 16 * (s1_ & 3));
+            }
+            const bf16x8* Bf = Bq[h & 1];
+            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wr[s][1], Bf[1], acc[nt], 0, 0, 0);
+            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wr[s][0], Bf[2], acc[nt], 0, 0, 0);
+            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wr[s][2], Bf[0], acc[nt], 0, 0, 0);
+            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wr[s][0], Bf[1], acc[nt], 0, 0, 0);
+            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wr[s][1], Bf[0], acc[nt], 0, 0, 0);
+            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wr[s][0], Bf[0], acc[nt], 0, 0, 0);
+            // side work of this half-step
+            if (h < 16) {
+                split_unit(reinterpret_cast<unsigned*>(xnxt), nt0, h >> 2, h & 3);
+                if ((h & 3) == 3) load_combo(next2, h >> 2);          // this combo's registers are free again
+            } else if (h == 16) split_halo(xnxt, nt0);
+            else if (h == 17) load_halo(next2);
+            if (h < 8) { epi_value(2 * h, b, t0); epi_value(2 * h + 1, b, t0); }
+            else epi_value(8 + h, b, t0);
+            // interleave: after the fragment reads, one MFMA then a handful of the side instructions, six times
+            __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+#pragma unroll
+            for (int kk = 0; kk < 6; ++kk) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#ifdef WM_STAMP
+#ifdef WM_STAMP_FINE
+            if (h == 16) { STAMP(tsa); tm[0] += tsa - ts0; }
+            if (h == 17) { STAMP(tsb); tm[1] += tsb - ts0; }
+            if (h == 18) { STAMP(tsb); tm[3] += tsb - ts0; }
+            if (h == 20) { STAMP(tsb); tm[5] += tsb - ts0; }
+#else
+            if (h == 3) { STAMP(tsa); tm[0] += tsa - ts0; }
+            if (h == 15) { STAMP(tsb); tm[1] += tsb - ts0; }
+#endif
+#endif
+        }
+        STAMP(ts1);
+        accp[0] = acc[0]; accp[1] = acc[1];
+        pb_ = b; pt0 = t0; pflag = 1.f;
+        STAMP(ts2);
+        lds_barrier();
+        STAMP(ts3);
+#ifdef WM_STAMP
+#ifdef WM_STAMP_FINE
+        tm[2] += ts1 - ts0; tm[4] += ts3 - ts2;
+#else
+        tm[2] += ts1 - ts0; tm[3] += ts2 - ts1; tm[4] += ts3 - ts2;
+#endif
+#endif
+        tile += tstep;
+        buf ^= 1;
+    }
+#ifdef WM_STAMP
+    if (g_wm_stamp && lane == 0) {
+        unsigned long long* d = g_wm_stamp + ((size_t)blockIdx.x * 4 + wave) * 6;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) d[i] = tm[i];
+    }
+#endif
+    if (pflag != 0.f) {                              // flush: the last tile's epilogue (its operand is already in e1r)
+#pragma unroll
+        for (int idx = 0; idx < 32; ++idx) epi_value(idx, -1, 0);
+    }
+    if (STATS) {
+        float* red = reinterpret_cast<float*>(Xb0);          // [2 column halves][2][64]
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { s1[j] = half_wave_sum(s1[j]); s2[j] = half_wave_sum(s2[j]); }
+        __syncthreads();
+        if (l31 == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = 32 * mt + mfma_row(r, half);
+                red[nh * 128 + co] = s1[r];
+                red[nh * 128 + 64 + co] = s2[r];
+            }
+        }
+        __syncthreads();
+        if (tid < 128) a.stats[(size_t)blockIdx.x * 128 + tid] = red[tid] + red[128 + tid];
+    }
+}
+
+template <int PRO, int EPI, bool STATS>
+int launch_conv64bf3(const Conv64Args& a, hipStream_t stream) {
+    constexpr size_t lds = (size_t)(2 * 3 * 130 * 72) * 2 + 6 * 64 * sizeof(float);
+    static bool attr_done = false;
+    auto kern = conv64bf3_kernel<PRO, EPI, STATS>;
     if (!attr_done) {
         WM_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done = true;
@@ -1302,8 +1628,8 @@ int wm_pack_w64_bf(const float* w, void* wpb, int mode, hipStream_t stream) {
 }
 
 // schedule of wm_conv64_bf: 0 = one wave per SIMD (128-column tiles), 1 = two-group ping-pong (64-column tiles)
-static int g_bf_schedule = 0;   // measured: the one-wave-per-SIMD schedule wins on every stats variant (MEM phase of the 64-column tiles dominates)
-int wm_set_conv_bf_schedule(int schedule, hipStream_t) { g_bf_schedule = schedule ? 1 : 0; return 0; }
+static int g_bf_schedule = 2;   // 0: phase-serial, 1: two-group ping-pong, 2: register-resident weights + interleaved pipeline (fastest, needs T % 128 == 0)
+int wm_set_conv_bf_schedule(int schedule, hipStream_t) { g_bf_schedule = (schedule >= 0 && schedule <= 2) ? schedule : 0; return 0; }
 
 int wm_conv64_bf(const float* x, const float* x2, const void* wpb, const float* pa, const float* pb, const float* pc,
                  const float* bias, const float* e1, const float* ea, const float* eb, float* y, float* stats,
@@ -1311,6 +1637,14 @@ int wm_conv64_bf(const float* x, const float* x2, const void* wpb, const float* 
     if (B <= 0 || T <= 0 || (T & 3)) return (int)hipErrorInvalidValue;
     Conv64Args a{x, x2, reinterpret_cast<const float*>(wpb), pa, pb, pc, bias, e1, ea, eb, y, stats, B, T};
     const bool st = stats != nullptr;
+    if (g_bf_schedule == 2 && (T & 127) == 0) {
+        if (pro == PRO_NONE && epi == EPI_BIAS) return st ? launch_conv64bf3<PRO_NONE, EPI_BIAS, true>(a, stream) : launch_conv64bf3<PRO_NONE, EPI_BIAS, false>(a, stream);
+        if (pro == PRO_BNRELU && epi == EPI_BIAS) return st ? launch_conv64bf3<PRO_BNRELU, EPI_BIAS, true>(a, stream) : launch_conv64bf3<PRO_BNRELU, EPI_BIAS, false>(a, stream);
+        if (pro == PRO_BNBWD && epi == EPI_RELUMASK && st) return launch_conv64bf3<PRO_BNBWD, EPI_RELUMASK, true>(a, stream);
+        if (pro == PRO_BNBWD && epi == EPI_ADD && !st) return launch_conv64bf3<PRO_BNBWD, EPI_ADD, false>(a, stream);
+        if (pro == PRO_BNBWD && epi == EPI_NONE && !st) return launch_conv64bf3<PRO_BNBWD, EPI_NONE, false>(a, stream);
+        return (int)hipErrorInvalidValue;
+    }
     if (g_bf_schedule == 1) {
         if (pro == PRO_NONE && epi == EPI_BIAS) return st ? launch_conv64bf2<PRO_NONE, EPI_BIAS, true>(a, stream) : launch_conv64bf2<PRO_NONE, EPI_BIAS, false>(a, stream);
         if (pro == PRO_BNRELU && epi == EPI_BIAS) return st ? launch_conv64bf2<PRO_BNRELU, EPI_BIAS, true>(a, stream) : launch_conv64bf2<PRO_BNRELU, EPI_BIAS, false>(a, stream);

@@ -52,75 +52,137 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
 }
 
 // ------------------------------------------------------------------------------ stem backward
-// g [B,64,T]; persistent blocks over (clip, 256-sample) tiles.
-//   ds[b,t]   = sum_{co,j} g[co,t-j+3] w[co][j]          (only if ds != nullptr)
-//   dw[co][j] = sum_{b,t} g[co,t] s[t+j-3] ; db[co] = sum g[co,t]   -> partial[block][64*8]
+// g [B,64,T]; persistent blocks over (clip, 256-sample) tiles, next tile prefetched into registers.
+//   dw[co][j] = sum_{b,t} g[co,t] s[t+j-3] ; db[co] = sum g[co,t]  -> on the fp32 matrix cores: M = co, K = time,
+//               N = 8 columns (7 taps + a column of ones for the bias) padded to 32     -> partial[block][64*8]
+//   ds[b,t]   = sum_{co,j} g[co,t-j+3] w[co][j]   (only if ds != nullptr; clips >= nds are skipped): VALU, register
+//               blocked 4 samples x 16 channels per thread, the four channel groups are summed through LDS.
 __global__ __launch_bounds__(256) void stem_bwd_kernel(const float* __restrict__ g, const float* __restrict__ s,
                                                        const float* __restrict__ w, float* __restrict__ ds,
-                                                       float* __restrict__ partial, int B, int T) {
-    constexpr int NT = 256, GS = NT + 8;             // g tile row: [3 halo][256][3 halo] at offset 1
+                                                       float* __restrict__ partial, int B, int T, int nds) {
+    constexpr int NT = 256, GS = NT + 8;             // g tile row: 3 halo | 256 | 3 halo starting at column 1; main part at 4
     extern __shared__ __align__(16) float smem[];
     float* gs = smem;                                // [64][GS]
-    float* ss = gs + 64 * GS;                        // [NT + 8]
-    float* ws = ss + NT + 8;                         // [64][8]
-    const int tid = threadIdx.x;
+    float* ss = gs + 64 * GS;                        // [NT + 40]: s[t0 - 3 + i]; zero padded so that B-operand reads stay in range
+    float* ws = ss + NT + 40;                        // [64][8]
+    float* dsp = ws + 512;                           // [4][NT] partial ds of the four channel groups
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
     for (int i = tid; i < 512; i += 256) ws[i] = ((i & 7) < 7) ? w[(i >> 3) * 7 + (i & 7)] : 0.f;
     const int tilesPerClip = (T + NT - 1) / NT, ntiles = B * tilesPerClip;
-    // reduction roles: thread -> (co = tid >> 2, jg = tid & 3) handles taps jg and jg + 4 (tap 7 == bias)
-    const int rco = tid >> 2, rj = tid & 3;
-    double accA = 0.0, accB = 0.0;      // cross-tile accumulation in fp64: these sums cancel heavily (bias gradient)
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    f32x16 acc[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
+    float4 sg[16];
+    float hg[2], sv[2];
+    auto load_tile = [&](int tile) {                 // branch-free (clamped addresses)
         const int b = tile / tilesPerClip, t0 = (tile % tilesPerClip) * NT;
         const float* gb = g + (size_t)b * 64 * T;
-        __syncthreads();
-        for (int i = tid; i < 64 * (NT / 4); i += 256) {
-            const int c = i / (NT / 4), q = i % (NT / 4), t = t0 + 4 * q;
-            float4 v = *reinterpret_cast<const float4*>(gb + (size_t)c * T + min(t, T - 4));   // branch-free load, masked below
-            if (t >= T) v = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int i = tid + k * 256, c = i >> 6, q = i & 63;
+            sg[k] = *reinterpret_cast<const float4*>(gb + (size_t)c * T + min(t0 + 4 * q, T - 4));
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int i = min(tid + k * 256, 64 * 6 - 1), c = i / 6, h = i % 6;
+            const int t = (h < 3) ? t0 - 3 + h : t0 + NT + (h - 3);
+            hg[k] = gb[(size_t)c * T + min(max(t, 0), T - 1)];
+            const int ts_ = t0 - 3 + tid + k * 256;
+            sv[k] = s[(size_t)b * T + min(max(ts_, 0), T - 1)];
+        }
+    };
+    auto write_tile = [&](int tile) {
+        const int t0 = (tile % tilesPerClip) * NT;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int i = tid + k * 256, c = i >> 6, q = i & 63;
+            float4 v = sg[k];
+            if (t0 + 4 * q >= T) v = make_float4(0.f, 0.f, 0.f, 0.f);
             *reinterpret_cast<float4*>(gs + c * GS + 4 + 4 * q) = v;
         }
-        for (int i = tid; i < 64 * 6; i += 256) {
-            const int c = i / 6, h = i % 6;
-            const int t = (h < 3) ? t0 - 3 + h : t0 + NT + (h - 3);
-            const float gv = gb[(size_t)c * T + min(max(t, 0), T - 1)];
-            gs[c * GS + ((h < 3) ? 1 + h : 4 + NT + (h - 3))] = (t >= 0 && t < T) ? gv : 0.f;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int i = tid + k * 256;
+            if (i < 64 * 6) {
+                const int c = i / 6, h = i % 6;
+                const int t = (h < 3) ? t0 - 3 + h : t0 + NT + (h - 3);
+                gs[c * GS + ((h < 3) ? 1 + h : 4 + NT + (h - 3))] = (t >= 0 && t < T) ? hg[k] : 0.f;
+            }
+            if (i < NT + 40) {
+                const int ts_ = t0 - 3 + i;
+                ss[i] = (i < NT + 6 && ts_ >= 0 && ts_ < T) ? sv[k] : 0.f;
+            }
         }
-        for (int i = tid; i < NT + 6; i += 256) {
-            const int t = t0 - 3 + i;
-            const float sv = s[(size_t)b * T + min(max(t, 0), T - 1)];
-            ss[i] = (t >= 0 && t < T) ? sv : 0.f;
+    };
+    int tile = blockIdx.x;
+    if (tile < ntiles) load_tile(tile);
+    __syncthreads();
+    if (tile < ntiles) write_tile(tile);
+    __syncthreads();
+    while (tile < ntiles) {
+        const int next = tile + gridDim.x;
+        if (next < ntiles) load_tile(next);
+        const int b = tile / tilesPerClip, t0 = (tile % tilesPerClip) * NT;
+        // ---- dw / db: this wave's 64 time steps.  A[i = co][k = t] = gs[co][t];  B[k = t][j] = s[t + j - 3] (j < 7), 1 (j == 7), 0
+        {
+            const float* ap = gs + l31 * GS + 4 + wave * 64 + half;
+            const float* bp = ss + wave * 64 + half + l31;        // ss[t - t0 + j] = s[t + j - 3]
+            const bool tapcol = l31 < 7, onecol = l31 == 7;
+#pragma unroll 8
+            for (int k2 = 0; k2 < 32; ++k2) {
+                const float sval = bp[2 * k2];
+                const float bv = tapcol ? sval : (onecol ? 1.f : 0.f);
+                acc[0] = mfma32(ap[2 * k2], bv, acc[0]);
+                acc[1] = mfma32(ap[32 * GS + 2 * k2], bv, acc[1]);
+            }
+        }
+        // ---- ds (Detector stem: gradient w.r.t. the watermarked half of the batch)
+        if (ds && b < nds) {
+            const int cg = wave, tq = lane;                       // 16 channels x 4 samples per thread
+            float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
+#pragma unroll 4
+            for (int cc = 0; cc < 16; ++cc) {
+                const int co = cg * 16 + cc;
+                const float4 ga = *reinterpret_cast<const float4*>(gs + co * GS + 4 * tq);         // t0+4tq-4 .. -1
+                const float4 gb4 = *reinterpret_cast<const float4*>(gs + co * GS + 4 * tq + 4);    // t0+4tq   .. +3
+                const float4 gc = *reinterpret_cast<const float4*>(gs + co * GS + 4 * tq + 8);     // t0+4tq+4 .. +7
+                const float4 w0 = *reinterpret_cast<const float4*>(ws + co * 8), w1 = *reinterpret_cast<const float4*>(ws + co * 8 + 4);
+                // gv[i] = g[co][t0 + 4tq - 3 + i], i = 0..9 ;  ds[t] = sum_j g[t + 3 - j] w[j]
+                const float gv[10] = {ga.y, ga.z, ga.w, gb4.x, gb4.y, gb4.z, gb4.w, gc.x, gc.y, gc.z};
+                const float wj[7] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z};
+#pragma unroll
+                for (int j = 0; j < 7; ++j) {
+                    o0 = fmaf(gv[6 - j], wj[j], o0); o1 = fmaf(gv[7 - j], wj[j], o1);
+                    o2 = fmaf(gv[8 - j], wj[j], o2); o3 = fmaf(gv[9 - j], wj[j], o3);
+                }
+            }
+            *reinterpret_cast<float4*>(dsp + cg * NT + 4 * tq) = make_float4(o0, o1, o2, o3);
         }
         __syncthreads();
-        if (ds) {
+        if (ds && b < nds) {
             const int t = t0 + tid;
-            if (t < T) {
-                float acc = 0.f;
-                const float* gp = gs + 4 + tid + 3;          // g[co][t + 3 - j]
-#pragma unroll 4
-                for (int co = 0; co < 64; ++co) {
+            if (t < T) ds[(size_t)b * T + t] = (dsp[tid] + dsp[NT + tid]) + (dsp[2 * NT + tid] + dsp[3 * NT + tid]);
+        }
+        if (next < ntiles) write_tile(next);
+        __syncthreads();
+        tile = next;
+    }
+    // fixed-order reduction of the four waves' [64 x 8] tiles
+    float* red = gs;
+    for (int wv = 0; wv < 4; ++wv) {
+        if (wave == wv && l31 < 8) {
 #pragma unroll
-                    for (int j = 0; j < 7; ++j) acc = fmaf(gp[co * GS - j], ws[co * 8 + j], acc);
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int o = (mt * 32 + mfma_row(r, half)) * 8 + l31;
+                    red[o] = (wv == 0) ? acc[mt][r] : red[o] + acc[mt][r];
                 }
-                ds[(size_t)b * T + t] = acc;
-            }
         }
-        {
-            const float* gp = gs + rco * GS + 4;
-            const float* sA = ss + rj;                        // s[t + j - 3] -> ss[t - t0 + j]
-            float a0 = 0.f, a1 = 0.f;
-            if (rj < 3) {
-#pragma unroll 8
-                for (int t = 0; t < NT; ++t) { const float gv = gp[t]; a0 = fmaf(gv, sA[t], a0); a1 = fmaf(gv, sA[t + 4], a1); }
-            } else {
-#pragma unroll 8
-                for (int t = 0; t < NT; ++t) { const float gv = gp[t]; a0 = fmaf(gv, sA[t], a0); a1 += gv; }
-            }
-            accA += (double)a0; accB += (double)a1;
-        }
+        __syncthreads();
     }
     float* out = partial + (size_t)blockIdx.x * 512;
-    out[rco * 8 + rj] = (float)accA;
-    out[rco * 8 + rj + 4] = (float)accB;
+    for (int i = tid; i < 512; i += 256) out[i] = red[i];
 }
 
 // out[i] (+)= sum_p partial[p*stride + i],  i < count
@@ -376,11 +438,12 @@ int wm_stem_fwd(const float* s, const float* w, const float* bias, float* y, int
     return 0;
 }
 
-// partial: >= 256*512 floats of scratch.  ds may be NULL (Generator stem: the clip is data).
+// partial: >= 256*512 floats of scratch.  ds may be NULL (Generator stem: the clip is data); only clips [0, nds) get a ds row
+// (Detector stem: the clean half of [watermarked; clean] needs no input gradient).
 int wm_stem_bwd(const float* g, const float* s, const float* w, float* ds, float* partial, float* dw, float* db, int B,
-                int T, int accumulate, hipStream_t stream) {
+                int T, int nds, int accumulate, hipStream_t stream) {
     if (T & 3) return (int)hipErrorInvalidValue;
-    constexpr size_t lds = (size_t)(64 * 264 + 264 + 512) * sizeof(float);
+    constexpr size_t lds = (size_t)(64 * 264 + 296 + 512 + 4 * 256) * sizeof(float);
     static bool attr_done = false;
     if (!attr_done) {
         WM_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(stem_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -388,7 +451,7 @@ int wm_stem_bwd(const float* g, const float* s, const float* w, float* ds, float
     }
     const int ntiles = B * ((T + 255) / 256);
     const int grid = ntiles < kNumCU ? ntiles : kNumCU;
-    hipLaunchKernelGGL(stem_bwd_kernel, dim3(grid), dim3(256), lds, stream, g, s, w, ds, partial, B, T);
+    hipLaunchKernelGGL(stem_bwd_kernel, dim3(grid), dim3(256), lds, stream, g, s, w, ds, partial, B, T, nds);
     WM_CHECK_LAUNCH();
     hipLaunchKernelGGL(stem_reduce_kernel, dim3(2), dim3(256), 0, stream, (const float*)partial, grid, dw, db, accumulate);
     WM_CHECK_LAUNCH();

@@ -38,8 +38,8 @@ class ResBlock(nn.Module):
 
 
 class _Stem(nn.Conv1d):
-    def forward(self, x):
-        return ops.StemFn.apply(x, self.weight, self.bias)
+    def forward(self, x, grad_rows=None):
+        return ops.StemFn.apply(x, self.weight, self.bias, grad_rows)
 
 
 class _Head1(nn.Conv1d):
@@ -88,8 +88,15 @@ class Detector(nn.Module):
         self.model = nn.Sequential(_Stem(1, 64, kernel_size=7, padding=3), ResBlock(64), ResBlock(64),
                                    _HeadN(64, output_dim, kernel_size=1))
 
-    def forward(self, x):
-        return self.model(x)
+    def forward(self, x, input_grad_rows=None):
+        """`input_grad_rows` (optional, not in the reference): only clips [0, input_grad_rows) get an input gradient --
+        the train step feeds [watermarked; clean] (py/main16.py:249) and the clean half is data."""
+        if input_grad_rows is None:
+            return self.model(x)
+        x = self.model[0](x, input_grad_rows)
+        for layer in list(self.model)[1:]:
+            x = layer(x)
+        return x
 
 
 def load_state_dict_strip_prefix(model, state_dict, prefix="_orig_mod."):

@@ -100,6 +100,15 @@ import os as _os
 _CONV = {"bf16x6": _os.environ.get("WM_CONV_BF16X6", "1") == "1"}
 
 
+def set_conv_bf_schedule(schedule: int):
+    """0: phase-serial kernel, 1: two-group ping-pong, 2: register-resident weights + interleaved split (csrc/conv64.hip)."""
+    lib.wm_set_conv_bf_schedule(int(schedule), None)
+
+
+if "WM_CONV_BF_SCHEDULE" in _os.environ:
+    set_conv_bf_schedule(int(_os.environ["WM_CONV_BF_SCHEDULE"]))
+
+
 def set_conv_bf16x6(on: bool):
     _CONV["bf16x6"] = bool(on)
 
@@ -225,12 +234,13 @@ class StemFn(torch.autograd.Function):
     """Conv1d(1, 64, 7, padding=3) -- py/main16.py:134 / :177."""
 
     @staticmethod
-    def forward(ctx, s, w, b):
+    def forward(ctx, s, w, b, grad_rows=None):
         s = _frames(s, "clip batch", 1)
         B, _, T = s.shape
         y = _f32(B, 64, T, device=s.device)
         lib.wm_stem_fwd(_p(s), _p(w), _p(b), _p(y), B, T, _stream())
         ctx.save_for_backward(s, w)
+        ctx.grad_rows = B if grad_rows is None else max(0, min(int(grad_rows), B))
         return y
 
     @staticmethod
@@ -238,11 +248,13 @@ class StemFn(torch.autograd.Function):
         s, w = ctx.saved_tensors
         g = g.contiguous()
         B, _, T = s.shape
-        ds = torch.empty_like(s) if ctx.needs_input_grad[0] else None
+        ds = None
+        if ctx.needs_input_grad[0]:        # rows >= grad_rows are known not to need a gradient (the clean half): left zero
+            ds = torch.empty_like(s) if ctx.grad_rows == B else torch.zeros_like(s)
         part = _f32(NCU * 512, device=s.device)
         dw, db = torch.empty_like(w), _f32(64, device=s.device)
-        lib.wm_stem_bwd(_p(g), _p(s), _p(w), _p(ds), _p(part), _p(dw), _p(db), B, T, 0, _stream())
-        return ds, dw, db
+        lib.wm_stem_bwd(_p(g), _p(s), _p(w), _p(ds), _p(part), _p(dw), _p(db), B, T, ctx.grad_rows, 0, _stream())
+        return ds, dw, db, None
 
 
 class Head1Fn(torch.autograd.Function):

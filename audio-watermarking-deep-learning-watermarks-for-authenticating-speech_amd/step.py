@@ -21,7 +21,7 @@ def forward_losses(generator, detector, s, message):
     delta_raw = generator(s, message)                                  # :244
     delta = L.postprocess(delta_raw)                                   # :245-247
     s_w = s + delta                                                    # :248
-    logits = detector(torch.cat([s_w, s], dim=0))                      # :249-250
+    logits = detector(torch.cat([s_w, s], dim=0), input_grad_rows=s.shape[0])                    # :249-250
     loc, bce = L.detection_losses(logits, message)                     # :252-264
     l1 = L.l1_to_zero(delta)                                           # :266
     mel = _mel(s, s_w)                                                 # :267

@@ -84,7 +84,7 @@ int wm_bn_bwd_finalize(const float* partials, int nparts, double count, const fl
 /* ---- stem / heads: Conv1d(1,64,7,p=3) :134,:177 ; Conv1d(64,1,1) :146 ; Conv1d(64,1+bits,1) :180 (+permute :186) */
 int wm_stem_fwd(const float* s, const float* w, const float* bias, float* y, int B, int T, wm_stream_t stream);
 int wm_stem_bwd(const float* g, const float* s, const float* w, float* ds, float* partial, float* dw, float* db, int B,
-                int T, int accumulate, wm_stream_t stream);
+                int T, int nds, int accumulate, wm_stream_t stream);   /* ds rows only for clips [0, nds) */
 int wm_head1_fwd(const float* x, const float* w, const float* bias, float* y, int B, int T, wm_stream_t stream);
 int wm_head1_bwd(const float* g, const float* x, const float* w, float* dx, float* partial, float* dw, float* db, int B,
                  int T, int accumulate, wm_stream_t stream);

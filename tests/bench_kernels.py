@@ -84,7 +84,7 @@ timeit("lstm_wgrad", lambda: lib.wm_lstm_wgrad(_p(xp), _p(x), _p(h), _p(lpart), 
 s = torch.randn(2 * B, 1, T, device=dev); ws = torch.randn(64, 1, 7, device=dev); X2 = torch.randn(2 * B, 64, T, device=dev); Y2 = torch.empty_like(X2)
 timeit("stem_fwd (2B)", lambda: lib.wm_stem_fwd(_p(s), _p(ws), _p(bias), _p(Y2), 2 * B, T, st), None, 2 * FR)
 sp = _f32(256 * 512, device=dev); dws = torch.empty_like(ws); ds = torch.empty_like(s)
-timeit("stem_bwd +ds (2B)", lambda: lib.wm_stem_bwd(_p(X2), _p(s), _p(ws), _p(ds), _p(sp), _p(dws), _p(db), 2 * B, T, 0, st), None, 2 * FR)
+timeit("stem_bwd +ds (2B)", lambda: lib.wm_stem_bwd(_p(X2), _p(s), _p(ws), _p(ds), _p(sp), _p(dws), _p(db), 2 * B, T, 2 * B, 0, st), None, 2 * FR)
 w17 = torch.randn(17, 64, 1, device=dev); b17 = torch.randn(17, device=dev); lg = _f32(2 * B, T, 17, device=dev)
 timeit("headN_fwd (2B)", lambda: lib.wm_headN_fwd(_p(X2), _p(w17), _p(b17), _p(lg), 2 * B, T, 17, st), None, 2 * FR * 1.27)
 hp = _f32(256 * (17 * 64 + 17), device=dev); dw17 = torch.empty_like(w17); db17 = _f32(17, device=dev)
