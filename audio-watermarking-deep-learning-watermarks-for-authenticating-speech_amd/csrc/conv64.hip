@@ -832,12 +832,23 @@ int launch_conv64bf(const Conv64Args& a, hipStream_t stream) {
 #ifndef WM_LOAD_H
 #define WM_LOAD_H 17
 #endif
+#ifndef WM_XCD_MAP
+#define WM_XCD_MAP 1
+#endif
 #ifndef WM_TILE_CONTIG
 #define WM_TILE_CONTIG 0
 #endif
 #ifndef WM_NT_STORE
 #define WM_NT_STORE 0
 #endif
+// XCD-aware workgroup -> tile-slot map.  Workgroups are dealt round-robin to the 8 XCDs (blockIdx % 8), each with its
+// own L2.  Giving XCD x the 1/8 of the tile sequence [x*G/8, (x+1)*G/8) makes time-adjacent tiles share an L2, so the
+// halo columns (a 128-B line per channel per side, +50 % fetched bytes otherwise) and the neighbours' lines hit in L2.
+__device__ __forceinline__ int xcd_slot() {
+    const int g = gridDim.x, b = blockIdx.x;
+    return (g & 7) ? b : (b & 7) * (g >> 3) + (b >> 3);
+}
+
 __device__ __forceinline__ void lds_barrier() {          // s_barrier without draining vmcnt (global stores/prefetches stay in flight)
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
@@ -901,7 +912,7 @@ __global__ __launch_bounds__(256) void conv64bf3_kernel(Conv64Args a) {
     const int tend = min(tile + chunk, ntiles);
 #else
     const int tstep = gridDim.x, tend = ntiles;
-    int tile = blockIdx.x;                        // grid <= ntiles
+    int tile = WM_XCD_MAP ? xcd_slot() : (int)blockIdx.x;        // grid <= ntiles
 #endif
     load_tile(min(tile, ntiles - 1));
     if (tid < 64) {
@@ -1392,19 +1403,25 @@ __global__ __launch_bounds__(256) void wgrad64bf_kernel(Wgrad64Args a) {
 #pragma unroll
     for (int i = 0; i < NV; ++i) bsum[i] = 0.f;
 
-    auto load_tile = [&](int tile) {            // branch-free
+    // global -> register staging in NV + 1 pieces: the main loop issues one piece per MFMA block (a 64..96-KB burst per
+    // CU backs up the memory pipeline and blocks the wave at issue for thousands of cycles; see conv64bf3_kernel)
+    auto load_piece = [&](int tile, int i) {    // branch-free
         const int b = tile / tilesPerClip, t0 = (tile - b * tilesPerClip) * NT;
         const size_t base = (size_t)b * 64 * T;
-#pragma unroll
-        for (int i = 0; i < NV; ++i) {
+        if (i < NV) {
             const int idx = tid + i * 256, c = idx / QR, q = idx % QR;
             const int t = min(t0 + 4 * q, T - 4);
             sg[i] = *reinterpret_cast<const float4*>(a.g + base + (size_t)c * T + t);
             if (GTWO) sg2[i] = *reinterpret_cast<const float4*>(a.g2 + base + (size_t)c * T + t);
             sx[i] = *reinterpret_cast<const float4*>(a.x + base + (size_t)c * T + t);
+        } else {
+            const int hc = (tid & 127) >> 1, hh = tid & 1;
+            hx = a.x[base + (size_t)hc * T + min(max(hh ? t0 + NT : t0 - 1, 0), T - 1)];
         }
-        const int hc = (tid & 127) >> 1, hh = tid & 1;
-        hx = a.x[base + (size_t)hc * T + min(max(hh ? t0 + NT : t0 - 1, 0), T - 1)];
+    };
+    auto load_tile = [&](int tile) {
+#pragma unroll
+        for (int i = 0; i <= NV; ++i) load_piece(tile, i);
     };
     auto put4 = [&](unsigned short* dst, int stride_p, float v0, float v1, float v2, float v3) {
         unsigned a0, a1, a2, b0, b1, b2;
@@ -1452,7 +1469,7 @@ __global__ __launch_bounds__(256) void wgrad64bf_kernel(Wgrad64Args a) {
         }
     };
 
-    int tile = blockIdx.x;
+    int tile = WM_XCD_MAP ? xcd_slot() : (int)blockIdx.x;
     if (tile < ntiles) load_tile(tile);
     if (tid < 64) {
         Cs[tid] = GTWO ? a.ga[tid] : 0.f;
@@ -1480,8 +1497,8 @@ __global__ __launch_bounds__(256) void wgrad64bf_kernel(Wgrad64Args a) {
 
     while (tile < ntiles) {
         const int next = tile + gridDim.x;
-        if (next < ntiles) load_tile(next);
-#pragma unroll 1
+        const int nextc = min(next, ntiles - 1);         // clamped: a tile past the end is loaded (valid memory) but never written
+#pragma unroll
         for (int ss = 0; ss < 2; ++ss) {                 // this wave's 32 time steps = 2 k-blocks of 16
             const int e0 = wave * 32 + ss * 16 + 8 * half;
             bf16x8 A[2][NP];
@@ -1519,9 +1536,11 @@ __global__ __launch_bounds__(256) void wgrad64bf_kernel(Wgrad64Args a) {
                     WM_MM6(acc[1][mt][nt], Bc)
                     WM_MM6(acc[2][mt][nt], Br)
 #undef WM_MM6
+                    load_piece(nextc, (ss * 2 + nt) * 2 + mt);       // pieces 0..7 ride along the 8 MFMA blocks
                 }
             }
         }
+        load_piece(nextc, NV);
         __syncthreads();
         if (next < ntiles) write_tile(next);
         __syncthreads();
