@@ -123,11 +123,19 @@ def main():
             raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     import torch.distributed as dist
+    # rehearsal knobs (not used by the driver): WM_BENCH_SHARE_GPU=1 lets several ranks share one card and
+    # WM_DIST_BACKEND=gloo replaces RCCL, so the N>1 code path can be exercised on a one-GPU box
+    if os.environ.get("WM_BENCH_SHARE_GPU") == "1":
+        local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        backend = os.environ.get("WM_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import awm_amd
     from awm_amd import distributed as wmd
@@ -194,7 +202,8 @@ def main():
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-    total_loss = float(out["total"]) if args.mode == "train" else float(out["delta_rms"].mean())
+    tot = out["total"] if args.mode == "train" else out["delta_rms"].mean()
+    total_loss = float(tot.detach()) if torch.is_tensor(tot) else float(tot)
     assert total_loss == total_loss, "NaN"
 
     if rank == 0:
