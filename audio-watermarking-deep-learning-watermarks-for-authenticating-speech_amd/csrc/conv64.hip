@@ -26,7 +26,7 @@ __device__ unsigned long long* g_wm_stamp = nullptr;
 namespace {
 
 enum { PRO_NONE = 0, PRO_BNRELU = 1, PRO_ADDVEC = 2, PRO_BNBWD = 3 };
-enum { EPI_BIAS = 0, EPI_RELUMASK = 1, EPI_ADD = 2, EPI_NONE = 3 };
+enum { EPI_BIAS = 0, EPI_RELUMASK = 1, EPI_ADD = 2, EPI_NONE = 3, EPI_BNADDRELU = 4 };   // 4: relu(e1 + (acc + bias) * ea + eb), conv64bf3 only
 
 struct Conv64Args {
     const float* x;     // [B,64,T] primary input
@@ -858,7 +858,7 @@ __global__ __launch_bounds__(256) void conv64bf3_kernel(Conv64Args a) {
     constexpr int KW = 3, NT = 128, ROWS = NT + 2, PITCH = 72, NP = 3, NC = 4;
     constexpr int XBUF = NP * ROWS * PITCH;               // bf16 elements per input image
     constexpr bool TWO = (PRO == PRO_BNBWD);
-    constexpr bool E1 = (EPI == EPI_RELUMASK || EPI == EPI_ADD);
+    constexpr bool E1 = (EPI == EPI_RELUMASK || EPI == EPI_ADD || EPI == EPI_BNADDRELU);
     extern __shared__ __align__(16) unsigned char smem_raw[];
     unsigned short* Xb0 = reinterpret_cast<unsigned short*>(smem_raw);             // 2 x [NP][ROWS][PITCH]
     float* Cs = reinterpret_cast<float*>(Xb0 + 2 * XBUF);                           // [6][64]
@@ -919,9 +919,9 @@ __global__ __launch_bounds__(256) void conv64bf3_kernel(Conv64Args a) {
         Cs[tid] = (PRO == PRO_BNRELU || PRO == PRO_BNBWD) ? a.pa[tid] : 0.f;
         Cs[64 + tid] = (PRO == PRO_BNRELU || PRO == PRO_BNBWD) ? a.pb[tid] : 0.f;
         Cs[128 + tid] = (PRO == PRO_BNBWD) ? a.pc[tid] : 0.f;
-        Cs[192 + tid] = (PRO == PRO_BNBWD) ? a.pb[64 + tid] : ((EPI == EPI_BIAS && a.bias) ? a.bias[tid] : 0.f);
-        Cs[256 + tid] = (EPI == EPI_RELUMASK) ? a.ea[tid] : 0.f;
-        Cs[320 + tid] = (EPI == EPI_RELUMASK) ? a.eb[tid] : 0.f;
+        Cs[192 + tid] = (PRO == PRO_BNBWD) ? a.pb[64 + tid] : (((EPI == EPI_BIAS || EPI == EPI_BNADDRELU) && a.bias) ? a.bias[tid] : 0.f);
+        Cs[256 + tid] = (EPI == EPI_RELUMASK || EPI == EPI_BNADDRELU) ? a.ea[tid] : 0.f;
+        Cs[320 + tid] = (EPI == EPI_RELUMASK || EPI == EPI_BNADDRELU) ? a.eb[tid] : 0.f;
     }
     __syncthreads();
     // per-thread prologue constants (the staging channels never change)
@@ -1010,11 +1010,8 @@ __global__ __launch_bounds__(256) void conv64bf3_kernel(Conv64Args a) {
         if (EPI == EPI_BIAS) v += Cs[192 + co];
         if (EPI == EPI_RELUMASK) { q = e1r[idx]; v = (fmaf(q, Cs[256 + co], Cs[320 + co]) > 0.f) ? v : 0.f; }
         if (EPI == EPI_ADD) v += e1r[idx];
-#ifndef WM_X_NOSTORE
+        if (EPI == EPI_BNADDRELU) v = fmaxf(e1r[idx] + fmaf(v + Cs[192 + co], Cs[256 + co], Cs[320 + co]), 0.f);   // = wm_bn_add_relu of the biased conv
         (a.y + sidx(nt, r))[loff] = v;
-#else
-        if (v == 123.456f) (a.y + sidx(nt, r))[loff] = v;
-#endif
         if (STATS) { s1[r] = fmaf(pflag, v, s1[r]); s2[r] = fmaf(pflag * v, (EPI == EPI_RELUMASK) ? q : v, s2[r]); }
         if (E1 && cb >= 0)
             e1r[idx] = (a.e1 + ((size_t)cb * 64 + 32 * mt + (r & 3) + 8 * (r >> 2)) * T + ct0 + 64 * nh + 32 * nt)[loff];
@@ -1657,6 +1654,7 @@ int wm_conv64_bf(const float* x, const float* x2, const void* wpb, const float* 
     Conv64Args a{x, x2, reinterpret_cast<const float*>(wpb), pa, pb, pc, bias, e1, ea, eb, y, stats, B, T};
     const bool st = stats != nullptr;
     if (g_bf_schedule == 2 && (T & 127) == 0) {
+        if (pro == PRO_BNRELU && epi == EPI_BNADDRELU && !st) return launch_conv64bf3<PRO_BNRELU, EPI_BNADDRELU, false>(a, stream);
         if (pro == PRO_NONE && epi == EPI_BIAS) return st ? launch_conv64bf3<PRO_NONE, EPI_BIAS, true>(a, stream) : launch_conv64bf3<PRO_NONE, EPI_BIAS, false>(a, stream);
         if (pro == PRO_BNRELU && epi == EPI_BIAS) return st ? launch_conv64bf3<PRO_BNRELU, EPI_BIAS, true>(a, stream) : launch_conv64bf3<PRO_BNRELU, EPI_BIAS, false>(a, stream);
         if (pro == PRO_BNBWD && epi == EPI_RELUMASK && st) return launch_conv64bf3<PRO_BNBWD, EPI_RELUMASK, true>(a, stream);

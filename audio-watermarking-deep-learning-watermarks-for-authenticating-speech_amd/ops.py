@@ -97,12 +97,13 @@ def _on_side(inputs, fn):
 # k3 convolutions (forward + data gradient): native fp32 MFMA, or the bf16x6 split build (fp32-grade error on the
 # bf16 matrix cores, see csrc/conv64.hip).  WM_CONV_BF16X6=0/1 in the environment overrides the default.
 import os as _os
-_CONV = {"bf16x6": _os.environ.get("WM_CONV_BF16X6", "1") == "1"}
+_CONV = {"bf16x6": _os.environ.get("WM_CONV_BF16X6", "1") == "1", "schedule": 2}
 
 
 def set_conv_bf_schedule(schedule: int):
     """0: phase-serial kernel, 1: two-group ping-pong, 2: register-resident weights + interleaved split (csrc/conv64.hip)."""
     lib.wm_set_conv_bf_schedule(int(schedule), None)
+    _CONV["schedule"] = int(schedule)
 
 
 if "WM_CONV_BF_SCHEDULE" in _os.environ:
@@ -163,6 +164,10 @@ class ResBlockFn(torch.autograd.Function):
             lib.wm_bn_eval_scale_shift(_p(g1), _p(be1), _p(rm1), _p(rv1), BN_EPS, _p(sc1), _p(sh1), st)
             lib.wm_bn_eval_scale_shift(_p(g2), _p(be2), _p(rm2), _p(rv2), BN_EPS, _p(sc2), _p(sh2), st)
             _conv3(x, None, w1, 0, None, None, None, b1, None, None, None, y1, None, B, T, 0, 0)
+            if not any(ctx.needs_input_grad) and _CONV["bf16x6"] and _CONV["schedule"] == 2 and T % 128 == 0:
+                # inference: BN2 + residual add + ReLU ride in conv2's epilogue -- the block is two launches
+                _conv3(y1, None, w2, 0, sc1, sh1, None, b2, x, sc2, sh2, out, None, B, T, 1, 4)
+                return out
             _conv3(y1, None, w2, 0, sc1, sh1, None, b2, None, None, None, y2, None, B, T, 1, 0)
             # saved (mean, invstd) for an eval-mode backward = running statistics
             mu1.copy_(rm1); is1.copy_(torch.rsqrt(rv1 + BN_EPS)); mu2.copy_(rm2); is2.copy_(torch.rsqrt(rv2 + BN_EPS))

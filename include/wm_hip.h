@@ -45,10 +45,14 @@ int wm_conv64(const float* x, const float* x2, const float* wp, const float* pa,
 /* bf16x6 build of the k3 convolution: every fp32 operand is split into three bf16 pieces in LDS and the six piece
  * products of weight >= 2^-16 are accumulated in fp32 on the bf16 matrix cores (fp32-grade error, 6/16 of the fp32 MFMA
  * time).  Same pro / epi / stats contract as wm_conv64 with KW = 3; wpb [3][3][64][64] uint16 from wm_pack_w64_bf
- * (mode 0 Conv1d fwd | 1 Conv1d dgrad). */
+ * (mode 0 Conv1d fwd | 1 Conv1d dgrad).  One more epilogue exists here only, for inference (py/main16.py:124-125 in
+ * eval mode as two launches): (pro 1, epi 4, stats NULL) y = relu(e1 + (conv + bias[c]) * ea[c] + eb[c]), i.e. the
+ * second conv of a ResBlock with BatchNorm2 (folded running statistics), the residual add and the ReLU in its epilogue;
+ * needs schedule 2 and T % 128 == 0 (hipErrorInvalidValue otherwise). */
 int wm_pack_w64_bf(const float* w, void* wpb, int mode, wm_stream_t stream);
-/* schedule of wm_conv64_bf (process-wide knob for experiments; default 0): 0 one wave per SIMD, 128-column tiles |
- * 1 two groups of four waves half a period apart, 64-column tiles (the bf16 MFMA runs beside the partner's VALU work) */
+/* schedule of wm_conv64_bf (process-wide knob; default 2): 0 phase-serial, one wave per SIMD, 128-column tiles |
+ * 1 two groups of four waves half a period apart, 64-column tiles | 2 weight fragments resident in registers, input
+ * image double-buffered, split / deferred epilogue / prefetch interleaved with the MFMAs (T % 128 == 0, else 0 runs) */
 int wm_set_conv_bf_schedule(int schedule, wm_stream_t stream);
 int wm_conv64_bf(const float* x, const float* x2, const void* wpb, const float* pa, const float* pb, const float* pc,
                  const float* bias, const float* e1, const float* ea, const float* eb, float* y, float* stats,

@@ -128,6 +128,24 @@ def _resblock_state(seed):
     return sd
 
 
+@pytest.mark.parametrize("B,T", [(2, 1280), (1, 16000)])
+def test_resblock_inference_fused_epilogue(awm, dev, B, T):
+    """no-grad eval ResBlock = two launches (BN2 + residual + ReLU in conv2's epilogue, wm_conv64_bf epi 4): identical
+    to the three-launch path that autograd takes, and to the oracle (py/main16.py:124-125, eval mode)."""
+    sd = _resblock_state(21 + B)
+    x = rnd(B, 64, T, seed=13).abs() * 0.7
+    m = awm.ResBlock(64)
+    m.load_state_dict(sd)
+    m.to(dev).eval()
+    with torch.no_grad():
+        y_fused = m(x.to(dev))
+    y_unfused = m(x.to(dev).requires_grad_())          # an input gradient is wanted -> the unfused path runs
+    if awm.ops.conv_bf16x6():
+        assert torch.equal(y_fused, y_unfused.detach()), float((y_fused - y_unfused.detach()).abs().max())
+    yr = O.resblock({k: v.clone() for k, v in sd.items()}, "", x, False, {})
+    check(y_fused, yr, FWD_TOL, "fused eval resblock")
+
+
 @pytest.mark.parametrize("training", [False, True])
 @pytest.mark.parametrize("B,T", [(2, 1000), (1, 256), (3, 1284)])
 def test_resblock(awm, dev, training, B, T):
