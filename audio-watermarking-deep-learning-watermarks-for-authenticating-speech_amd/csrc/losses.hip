@@ -12,37 +12,66 @@ __device__ __forceinline__ float bce_logits(float x, float y) {
     return fmaxf(x, 0.f) - x * y + log1pf(expf(-fabsf(x)));
 }
 
-// partial[0][blk] = sum of detection terms, partial[1][blk] = sum of bit terms
+// Both BCE kernels walk one clip's [T][NO] logits in flat, coalesced order: grid = (chunks of 4096 elements, clips).
+// The channel o = idx % NO comes from a float reciprocal with a fix-up (idx < 2^23): the 64-bit div/mod per element of
+// the first version made these kernels 6x slower than the memory system allows.
+__device__ __forceinline__ int mod_small(int idx, int n, float inv_n) {
+    int q = (int)((float)idx * inv_n);
+    int r = idx - q * n;
+    if (r < 0) r += n;
+    if (r >= n) r -= n;
+    return r;
+}
+
+// partial[0][blk] = sum of detection terms, partial[1][blk] = sum of bit terms (blk = flat block index)
 __global__ __launch_bounds__(256) void bce_fwd_kernel(const float* __restrict__ logits, const long long* __restrict__ message,
                                                       int B, int R, int T, int NO, float* __restrict__ partial) {
     __shared__ float scratch[8];
-    const size_t total = (size_t)R * T * NO, per_clip = (size_t)T * NO;
+    const int r = blockIdx.y, per_clip = T * NO;
+    const float inv = 1.0f / (float)NO;
+    const long long msg = (r < B) ? message[r] : 0;
+    const float yl = r < B ? 1.f : 0.f;
+    const float* lp = logits + (size_t)r * per_clip;
     float sl = 0.f, sb = 0.f;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const int r = (int)(i / per_clip), o = (int)(i % NO);
-        const float x = logits[i];
-        if (o == 0) sl += bce_logits(x, r < B ? 1.f : 0.f);
-        else if (r < B) sb += bce_logits(x, (float)((message[r] >> (o - 1)) & 1));
+#pragma unroll 4
+    for (int k = 0; k < 16; ++k) {
+        const int idx = blockIdx.x * 4096 + k * 256 + threadIdx.x;
+        if (idx < per_clip) {
+            const int o = mod_small(idx, NO, inv);
+            const float x = lp[idx];
+            if (o == 0) sl += bce_logits(x, yl);
+            else if (r < B) sb += bce_logits(x, (float)((msg >> (o - 1)) & 1));
+        }
     }
     sl = block_sum<4>(sl, scratch);
     sb = block_sum<4>(sb, scratch + 4);
-    if (threadIdx.x == 0) { partial[blockIdx.x] = sl; partial[gridDim.x + blockIdx.x] = sb; }
+    const int blk = blockIdx.y * gridDim.x + blockIdx.x, nblk = gridDim.x * gridDim.y;
+    if (threadIdx.x == 0) { partial[blk] = sl; partial[nblk + blk] = sb; }
 }
 
 __global__ __launch_bounds__(256) void bce_bwd_kernel(const float* __restrict__ logits, const long long* __restrict__ message,
                                                       const float* __restrict__ g_loc, const float* __restrict__ g_bce,
                                                       int B, int R, int T, int NO, float* __restrict__ dlogits) {
-    const size_t total = (size_t)R * T * NO, per_clip = (size_t)T * NO;
+    const int r = blockIdx.y, per_clip = T * NO;
+    const float inv = 1.0f / (float)NO;
     const float kl = g_loc[0] / (float)((double)R * T);
     const float kb = (NO > 1) ? g_bce[0] / (float)((double)B * T * (NO - 1)) : 0.f;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const int r = (int)(i / per_clip), o = (int)(i % NO);
-        const float x = logits[i];
-        const float sg = 1.0f / (1.0f + expf(-x));
-        float d;
-        if (o == 0) d = kl * (sg - (r < B ? 1.f : 0.f));
-        else d = (r < B) ? kb * (sg - (float)((message[r] >> (o - 1)) & 1)) : 0.f;
-        dlogits[i] = d;
+    const long long msg = (r < B) ? message[r] : 0;
+    const float yl = r < B ? 1.f : 0.f;
+    const float* lp = logits + (size_t)r * per_clip;
+    float* dp = dlogits + (size_t)r * per_clip;
+#pragma unroll 4
+    for (int k = 0; k < 16; ++k) {
+        const int idx = blockIdx.x * 4096 + k * 256 + threadIdx.x;
+        if (idx < per_clip) {
+            const int o = mod_small(idx, NO, inv);
+            const float x = lp[idx];
+            const float sg = 1.0f / (1.0f + expf(-x));
+            float d;
+            if (o == 0) d = kl * (sg - yl);
+            else d = (r < B) ? kb * (sg - (float)((msg >> (o - 1)) & 1)) : 0.f;
+            dp[idx] = d;
+        }
     }
 }
 
@@ -87,11 +116,12 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
 
 extern "C" {
 
-// logits [R=2B,T,NO] (NO = 1 + bits); message [B] int64; partial: >= 2*1024 floats scratch.
+// logits [R=2B,T,NO] (NO = 1 + bits); message [B] int64; partial: >= 2 * R * ceil(T*NO/4096) floats scratch.
 int wm_bce_fwd(const float* logits, const long long* message, float* partial, float* loc_out, float* bce_out, int B, int R,
                int T, int NO, hipStream_t stream) {
-    const int grid = 1024;
-    hipLaunchKernelGGL(bce_fwd_kernel, dim3(grid), dim3(256), 0, stream, logits, message, B, R, T, NO, partial);
+    if ((long long)T * NO >= (1 << 23) || R <= 0 || R > 65535) return (int)hipErrorInvalidValue;
+    const int chunks = (T * NO + 4095) / 4096, grid = chunks * R;
+    hipLaunchKernelGGL(bce_fwd_kernel, dim3(chunks, R), dim3(256), 0, stream, logits, message, B, R, T, NO, partial);
     WM_CHECK_LAUNCH();
     hipLaunchKernelGGL(sum_scale2_kernel, dim3(1), dim3(256), 0, stream, (const float*)partial, grid, 1.0 / ((double)R * T), loc_out);
     WM_CHECK_LAUNCH();
@@ -106,7 +136,9 @@ int wm_bce_fwd(const float* logits, const long long* message, float* partial, fl
 // g_loc / g_bce: device scalars holding d(total)/d(loc), d(total)/d(bce)
 int wm_bce_bwd(const float* logits, const long long* message, const float* g_loc, const float* g_bce, float* dlogits, int B,
                int R, int T, int NO, hipStream_t stream) {
-    hipLaunchKernelGGL(bce_bwd_kernel, dim3(2048), dim3(256), 0, stream, logits, message, g_loc, g_bce, B, R, T, NO, dlogits);
+    if ((long long)T * NO >= (1 << 23) || R <= 0 || R > 65535) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(bce_bwd_kernel, dim3((T * NO + 4095) / 4096, R), dim3(256), 0, stream, logits, message, g_loc, g_bce, B, R, T,
+                       NO, dlogits);
     WM_CHECK_LAUNCH();
     return 0;
 }

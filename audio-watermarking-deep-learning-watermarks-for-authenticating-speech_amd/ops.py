@@ -510,7 +510,7 @@ class BCEFn(torch.autograd.Function):
         if R != 2 * B:
             raise ValueError(f"logits must hold [watermarked; clean] = 2*B clips, got {R} for B={B}")
         dev = logits.device
-        part = _f32(2048, device=dev)
+        part = _f32(2 * R * ((T * NO + 4095) // 4096), device=dev)
         out = torch.zeros(2, dtype=torch.float32, device=dev)
         lib.wm_bce_fwd(_p(logits), _p(message), _p(part), _p(out[0]), _p(out[1]), B, R, T, NO, _stream())
         ctx.save_for_backward(logits, message)

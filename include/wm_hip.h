@@ -127,7 +127,8 @@ int wm_loud_loss(const float* clean, const float* wm, float thresh, float* gfram
 int wm_hf_penalty(const float* delta, int kcut, float* gframes, float* partial, float* loss_out, float* dsig, int B, int T,
                   wm_stream_t stream);
 
-/* ---- point-wise losses :252-266 and the optimizer update :504,:278 ------------------------------------------ */
+/* ---- point-wise losses :252-266 and the optimizer update :504,:278 ------------------------------------------
+ * wm_bce_*: logits [R = 2B][T][NO]; partial: >= 2 * R * ceil(T*NO / 4096) floats of scratch; T*NO < 2^23, R <= 65535 */
 int wm_bce_fwd(const float* logits, const long long* message, float* partial, float* loc_out, float* bce_out, int B, int R,
                int T, int NO, wm_stream_t stream);
 int wm_bce_bwd(const float* logits, const long long* message, const float* g_loc, const float* g_bce, float* dlogits, int B,
