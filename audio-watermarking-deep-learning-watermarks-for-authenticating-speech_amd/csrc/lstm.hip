@@ -99,10 +99,25 @@ __device__ __forceinline__ float gate_act(float x, bool is_g) {
     return is_g ? fmaf(2.0f, s, -1.0f) : s;
 }
 
+// acc += w * {v[lane k], v[lane k+1]}: the two broadcast values travel through an SGPR pair (v_readlane), which
+// v_pk_fma_f32 takes directly as an operand -- no LDS return traffic, no VGPR copies
+template <typename T2>
+__device__ __forceinline__ T2 pk_fma_lanes(T2 w, float v, int k, T2 acc) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane(__float_as_int(v), k);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane(__float_as_int(v), k + 1);
+    const unsigned long long pr = ((unsigned long long)hi << 32) | lo;
+    asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(w), "s"(pr));
+    return acc;
+}
+
+#ifndef WM_LSTM_HS
+#define WM_LSTM_HS 32
+#endif
 template <bool SAVE>
 __global__ __launch_bounds__(256) void lstm_fwd_kernel(const float* xp, const float* __restrict__ w_hh,
                                                        float* __restrict__ hout, float* gates,   // gates may alias xp
                                                        float* __restrict__ cst, int T) {
+    constexpr int HS = WM_LSTM_HS;                  // h values taken through SGPRs (multiple of 8, power of two), rest via LDS broadcast
     __shared__ __align__(16) float hs[2][64];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q = lane & 3, ul = lane >> 2, u = wave * 16 + ul, n = q * 64 + u, np = wave * 64 + lane;
@@ -135,15 +150,30 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(const float* xp, const fl
         for (int s = 0; s < 16; ++s) {
             const int t = t0 + s;
             if (t < T) {                                   // uniform across the workgroup
+                // h reaches the lanes two ways at once.  Broadcasting all 64 values to all 256 lanes through LDS reads
+                // is 64 KB per step = 512 cycles of the CU's LDS return path -- the step's bottleneck.  So the first
+                // HS values come as ONE ds_read_b32 per wave + v_readlane into SGPRs (VALU work, scalar FMA operands)
+                // and only the rest as broadcast ds_read_b128: LDS and VALU each carry about half.
+                const float hv = hs[s & 1][lane & (HS - 1)];
                 const float4* hp = reinterpret_cast<const float4*>(hs[s & 1]);
+                float4 hq[(64 - HS) / 4];
+#pragma unroll
+                for (int k = 0; k < (64 - HS) / 4; ++k) hq[k] = hp[HS / 4 + k];
                 v2f a01 = v2f{xin[s], 0.f}, a23 = v2f{0.f, 0.f}, b01 = a23, b23 = a23;
 #pragma unroll
-                for (int k = 0; k < 16; k += 2) {
-                    const float4 h0 = hp[k], h1 = hp[k + 1];
-                    a01 = __builtin_elementwise_fma(wr[2 * k], v2f{h0.x, h0.y}, a01);
-                    a23 = __builtin_elementwise_fma(wr[2 * k + 1], v2f{h0.z, h0.w}, a23);
-                    b01 = __builtin_elementwise_fma(wr[2 * k + 2], v2f{h1.x, h1.y}, b01);
-                    b23 = __builtin_elementwise_fma(wr[2 * k + 3], v2f{h1.z, h1.w}, b23);
+                for (int k = 0; k < HS; k += 8) {
+                    a01 = pk_fma_lanes(wr[k / 2], hv, k, a01);
+                    a23 = pk_fma_lanes(wr[k / 2 + 1], hv, k + 2, a23);
+                    b01 = pk_fma_lanes(wr[k / 2 + 2], hv, k + 4, b01);
+                    b23 = pk_fma_lanes(wr[k / 2 + 3], hv, k + 6, b23);
+                }
+#pragma unroll
+                for (int k = 0; k < (64 - HS) / 4; k += 2) {
+                    const float4 h0 = hq[k], h1 = hq[k + 1];
+                    a01 = __builtin_elementwise_fma(wr[HS / 2 + 2 * k], v2f{h0.x, h0.y}, a01);
+                    a23 = __builtin_elementwise_fma(wr[HS / 2 + 2 * k + 1], v2f{h0.z, h0.w}, a23);
+                    b01 = __builtin_elementwise_fma(wr[HS / 2 + 2 * k + 2], v2f{h1.x, h1.y}, b01);
+                    b23 = __builtin_elementwise_fma(wr[HS / 2 + 2 * k + 3], v2f{h1.z, h1.w}, b23);
                 }
                 const v2f sm = (a01 + a23) + (b01 + b23);
                 const float act = gate_act(sm.x + sm.y, is_g);
@@ -187,6 +217,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(const float* xp, const fl
 __global__ __launch_bounds__(256) void lstm_bwd_kernel(float* __restrict__ gates, const float* __restrict__ cst,
                                                        const float* __restrict__ dh_out, const float* __restrict__ w_hh,
                                                        int T) {
+    constexpr int HS = WM_LSTM_HS;
     __shared__ __align__(16) float das[4][64];      // wave-private da vectors
     __shared__ __align__(16) float part[2][64][4];  // [buffer][k][wave] partial dh
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -240,13 +271,23 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(float* __restrict__ gates
                 gb[(size_t)t * 256] = da;
                 das[wave][lane] = da;                       // same wave reads it back: no barrier needed
                 __builtin_amdgcn_wave_barrier();
+                // the wave's own 64 da values: the first HS straight out of the register (v_readlane -> SGPR-pair FMA
+                // operands), the rest as broadcast LDS reads -- VALU and the LDS return path share the load (see lstm_fwd)
                 const float4* dp = reinterpret_cast<const float4*>(das[wave]);
+                float4 dq[(64 - HS) / 4];
+#pragma unroll
+                for (int k = 0; k < (64 - HS) / 4; ++k) dq[k] = dp[HS / 4 + k];
                 v2f a01 = v2f{0.f, 0.f}, a23 = a01;
 #pragma unroll
-                for (int k = 0; k < 16; ++k) {
-                    const float4 d = dp[k];
-                    a01 = __builtin_elementwise_fma(wt[2 * k], v2f{d.x, d.y}, a01);
-                    a23 = __builtin_elementwise_fma(wt[2 * k + 1], v2f{d.z, d.w}, a23);
+                for (int k = 0; k < HS; k += 4) {
+                    a01 = pk_fma_lanes(wt[k / 2], da, k, a01);
+                    a23 = pk_fma_lanes(wt[k / 2 + 1], da, k + 2, a23);
+                }
+#pragma unroll
+                for (int k = 0; k < (64 - HS) / 4; ++k) {
+                    const float4 d = dq[k];
+                    a01 = __builtin_elementwise_fma(wt[HS / 2 + 2 * k], v2f{d.x, d.y}, a01);
+                    a23 = __builtin_elementwise_fma(wt[HS / 2 + 2 * k + 1], v2f{d.z, d.w}, a23);
                 }
                 const v2f sm = a01 + a23;
                 part[pb ^ 1][lane][wave] = sm.x + sm.y;
