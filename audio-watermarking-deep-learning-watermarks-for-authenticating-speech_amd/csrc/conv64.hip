@@ -566,20 +566,6 @@ __global__ void wgrad64_reduce_kernel(const float* __restrict__ partial, int npa
 // LDS images are channel-minor ([time][channel] and [tap][cout][cin], 144-B pitch) so that an MFMA fragment
 // (8 consecutive k = 8 input channels) is one aligned ds_read_b128.
 // ---------------------------------------------------------------------------------------------
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ void split3_pair(float a, float b, unsigned& p0, unsigned& p1, unsigned& p2) {
-    bf16x2 h = {(__bf16)a, (__bf16)b};
-    p0 = __builtin_bit_cast(unsigned, h);
-    a -= __uint_as_float(p0 << 16); b -= __uint_as_float(p0 & 0xffff0000u);
-    bf16x2 m = {(__bf16)a, (__bf16)b};
-    p1 = __builtin_bit_cast(unsigned, m);
-    a -= __uint_as_float(p1 << 16); b -= __uint_as_float(p1 & 0xffff0000u);
-    bf16x2 l = {(__bf16)a, (__bf16)b};
-    p2 = __builtin_bit_cast(unsigned, l);
-}
-
 #ifndef WM_LOADPOS
 #define WM_LOADPOS 1
 #endif

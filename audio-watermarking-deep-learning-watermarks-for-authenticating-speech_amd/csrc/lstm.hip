@@ -212,6 +212,169 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(const float* xp, const fl
     }
 }
 
+// ------------------------------------------------------ recurrence fwd with the input projection inside
+// Same recurrence as lstm_fwd_kernel, but xp = W_ih x + b is never materialised in HBM (4.2 GB written by
+// lstm_xproj and read back here at B = 256).  While the workgroup steps through 32-step chunk c it also computes chunk
+// c+1's projection [32 steps x 256 gate rows] on the bf16 matrix cores (bf16x6 split, fp32-grade; a separate pipe from
+// the VALU the recurrence runs on): 48 MFMAs per wave dealt two per step between the recurrence's own instructions.
+// W_ih lives in registers as 3-piece A fragments (96 VGPRs: this wave's 64 gate rows), the x tile goes global ->
+// registers (two chunks ahead) -> split -> LDS [step][channel] pieces (B fragments), results land in a double-buffered
+// LDS table xps[2][32][256(+1)] from which every lane picks its own gate row, one ds_read_b32 per step.
+template <bool SAVE>
+__global__ __launch_bounds__(256) void lstm_fwd_fused_kernel(const float* __restrict__ x, const float* __restrict__ w_ih,
+                                                             const float* __restrict__ b_ih, const float* __restrict__ b_hh,
+                                                             const float* __restrict__ w_hh, float* __restrict__ hout,
+                                                             float* __restrict__ gates, float* __restrict__ cst, int T) {
+    constexpr int HS = WM_LSTM_HS, CH = 32, XPP = 257, PITCH = 72, NP = 3;
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    float* xps = reinterpret_cast<float*>(smem_raw);                                  // [2][CH][XPP]
+    unsigned short* Xb = reinterpret_cast<unsigned short*>(xps + 2 * CH * XPP);       // [NP][CH][PITCH]
+    float* hsm = reinterpret_cast<float*>(Xb + NP * CH * PITCH);                      // [2][64]
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const int q = lane & 3, ul = lane >> 2, u = wave * 16 + ul, n = q * 64 + u, np = wave * 64 + lane;
+    v2f wr[32];                                    // W_hh row n of this lane
+#pragma unroll
+    for (int k = 0; k < 64; k += 4) {
+        const float4 v = *reinterpret_cast<const float4*>(w_hh + n * 64 + k);
+        wr[k / 2] = v2f{v.x, v.y};
+        wr[k / 2 + 1] = v2f{v.z, v.w};
+    }
+    // W_ih A fragments: row i = l31 of m-tile mt <-> gate column n' = wave*64 + mt*32 + l31, k = 16 ks + 8 half + j
+    bf16x8 Wi[2][4][NP];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const float* wp = w_ih + gate_row(wave * 64 + mt * 32 + l31) * 64 + 16 * ks + 8 * half;
+            const float4 v0 = *reinterpret_cast<const float4*>(wp), v1 = *reinterpret_cast<const float4*>(wp + 4);
+            unsigned a[4], m[4], l[4];
+            split3_pair(v0.x, v0.y, a[0], m[0], l[0]); split3_pair(v0.z, v0.w, a[1], m[1], l[1]);
+            split3_pair(v1.x, v1.y, a[2], m[2], l[2]); split3_pair(v1.z, v1.w, a[3], m[3], l[3]);
+            Wi[mt][ks][0] = __builtin_bit_cast(bf16x8, make_uint4(a[0], a[1], a[2], a[3]));
+            Wi[mt][ks][1] = __builtin_bit_cast(bf16x8, make_uint4(m[0], m[1], m[2], m[3]));
+            Wi[mt][ks][2] = __builtin_bit_cast(bf16x8, make_uint4(l[0], l[1], l[2], l[3]));
+        }
+    const float bias = b_ih[n] + b_hh[n];
+    if (tid < 128) hsm[tid] = 0.f;
+    float c = 0.f;
+    float* gb = SAVE ? gates + (size_t)b * T * 256 + np : nullptr;
+    float* cb = SAVE ? cst + (size_t)b * T * 64 + u : nullptr;
+    float* hb = hout + ((size_t)b * 64 + u) * T;
+    const bool is_g = (q == 2);
+
+    // x tile staging (one combo per thread): channel pair cp, time quad tq of the chunk
+    const int cp = wave * 8 + (lane & 7), tq = lane >> 3;
+    const float* xc = x + ((size_t)b * 64 + 2 * cp) * T + 4 * tq;
+    float4 sa, sb;
+    auto load_x = [&](int t0) {                    // clamped: chunks past the end re-read the last valid quad
+        const int t = min(t0, T - 4 - 4 * tq);
+        sa = *reinterpret_cast<const float4*>(xc + max(t, -4 * tq));
+        sb = *reinterpret_cast<const float4*>(xc + T + max(t, -4 * tq));
+    };
+    auto split_x = [&]() {
+        unsigned* X32 = reinterpret_cast<unsigned*>(Xb);
+        const float va[4] = {sa.x, sa.y, sa.z, sa.w}, vb[4] = {sb.x, sb.y, sb.z, sb.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            unsigned p0, p1, p2;
+            split3_pair(va[e], vb[e], p0, p1, p2);
+            const int o = (4 * tq + e) * (PITCH / 2) + cp;
+            X32[o] = p0; X32[CH * PITCH / 2 + o] = p1; X32[2 * (CH * PITCH / 2) + o] = p2;
+        }
+    };
+    f32x16 acc[2];
+    bf16x8 Bf[NP];
+    // m-th block of 6 MFMAs of a chunk's projection: m = ks * 2 + mt
+    auto mfma_block = [&](int m) {
+        const int ks = m >> 1, mt = m & 1;
+        if (mt == 0) {
+#pragma unroll
+            for (int p = 0; p < NP; ++p) Bf[p] = *reinterpret_cast<const bf16x8*>(Xb + (p * CH + l31) * PITCH + 16 * ks + 8 * half);
+        }
+        if (ks == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+        }
+        acc[mt] = mfma_bf16x6(Wi[mt][ks], Bf, acc[mt]);
+    };
+    auto store_xp = [&](int buf) {                 // D row = gate column (this wave's 64), D column = step
+        float* dst = xps + (buf * CH + l31) * XPP + wave * 64 + 4 * half;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dst[mt * 32 + (r & 3) + 8 * (r >> 2)] = acc[mt][r];
+    };
+
+    // ---- prologue: projection of chunk 0, x tile of chunk 1 in flight
+    load_x(0);
+    __syncthreads();
+    split_x();
+    load_x(CH);
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < 8; ++m) mfma_block(m);
+    store_xp(0);
+    __syncthreads();
+
+    float hk[4];
+    for (int t0 = 0, cbuf = 0; t0 < T; t0 += CH, cbuf ^= 1) {
+#pragma unroll
+        for (int s = 0; s < CH; ++s) {
+            const int t = t0 + s;
+            // ---- side work: projection of the next chunk (independent of the recurrence; no effect past the end)
+            if (s == 0) { split_x(); load_x(t0 + 2 * CH); }
+            if (s >= 2 && s < 26 && ((s - 2) % 3) == 0) mfma_block((s - 2) / 3);
+            if (s == 28) store_xp(cbuf ^ 1);
+            if (t < T) {                                   // uniform across the workgroup
+                const float xin = xps[(cbuf * CH + s) * XPP + np] + bias;
+                const float* hcur = hsm + (s & 1) * 64;
+                const float hv = hcur[lane & (HS - 1)];
+                const float4* hp = reinterpret_cast<const float4*>(hcur);
+                float4 hq[(64 - HS) / 4];
+#pragma unroll
+                for (int k = 0; k < (64 - HS) / 4; ++k) hq[k] = hp[HS / 4 + k];
+                v2f a01 = v2f{xin, 0.f}, a23 = v2f{0.f, 0.f}, b01 = a23, b23 = a23;
+#pragma unroll
+                for (int k = 0; k < HS; k += 8) {
+                    a01 = pk_fma_lanes(wr[k / 2], hv, k, a01);
+                    a23 = pk_fma_lanes(wr[k / 2 + 1], hv, k + 2, a23);
+                    b01 = pk_fma_lanes(wr[k / 2 + 2], hv, k + 4, b01);
+                    b23 = pk_fma_lanes(wr[k / 2 + 3], hv, k + 6, b23);
+                }
+#pragma unroll
+                for (int k = 0; k < (64 - HS) / 4; k += 2) {
+                    const float4 h0 = hq[k], h1 = hq[k + 1];
+                    a01 = __builtin_elementwise_fma(wr[HS / 2 + 2 * k], v2f{h0.x, h0.y}, a01);
+                    a23 = __builtin_elementwise_fma(wr[HS / 2 + 2 * k + 1], v2f{h0.z, h0.w}, a23);
+                    b01 = __builtin_elementwise_fma(wr[HS / 2 + 2 * k + 2], v2f{h1.x, h1.y}, b01);
+                    b23 = __builtin_elementwise_fma(wr[HS / 2 + 2 * k + 3], v2f{h1.z, h1.w}, b23);
+                }
+                const v2f sm = (a01 + a23) + (b01 + b23);
+                const float act = gate_act(sm.x + sm.y, is_g);
+                const float gi = quad_bcast<0>(act), gf = quad_bcast<1>(act), gg = quad_bcast<2>(act), go = quad_bcast<3>(act);
+                c = fmaf(gf, c, gi * gg);
+                const float h = go * tanh_s(c);
+                if (q == 0) hsm[((s + 1) & 1) * 64 + u] = h;
+                if (SAVE) {
+                    gb[(size_t)t * 256] = act;             // one contiguous 256-B segment per wave
+                    if (q == 1) cb[(size_t)t * 64] = c;
+                }
+                if (((s >> 2) & 3) == q) hk[s & 3] = h;
+                if ((s & 15) == 15)                        // every lane holds h for steps 4q .. 4q+3 of this 16-step group
+                    *reinterpret_cast<float4*>(hb + t0 + (s - 15) + 4 * q) = make_float4(hk[0], hk[1], hk[2], hk[3]);
+                __syncthreads();
+            }
+        }
+        // ragged tail (T % 16 != 0): flush what the last partial 16-step group produced
+        if (t0 + CH > T && (T & 15)) {
+            const int g0 = (T >> 4) << 4, tq0 = g0 + 4 * q;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (tq0 + j < T) hb[tq0 + j] = hk[j];
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------- recurrence bwd
 // gates: in = saved activations, out = pre-activation gradients da  [B,T,256] (column order n' = unit*4 + gate)
 __global__ __launch_bounds__(256) void lstm_bwd_kernel(float* __restrict__ gates, const float* __restrict__ cst,
@@ -501,6 +664,23 @@ int wm_lstm_fwd(const float* xp, const float* w_hh, float* hout, float* gates, f
     if (T & 3) return (int)hipErrorInvalidValue;
     if (gates && cst) hipLaunchKernelGGL(lstm_fwd_kernel<true>, dim3(B), dim3(256), 0, stream, xp, w_hh, hout, gates, cst, T);
     else hipLaunchKernelGGL(lstm_fwd_kernel<false>, dim3(B), dim3(256), 0, stream, xp, w_hh, hout, gates, cst, T);
+    WM_CHECK_LAUNCH();
+    return 0;
+}
+
+// Recurrence with the input projection inside (no xp tensor): x [B,64,T] -> hout; gates / cst as wm_lstm_fwd.
+int wm_lstm_fwd_fused(const float* x, const float* w_ih, const float* b_ih, const float* b_hh, const float* w_hh, float* hout,
+                      float* gates, float* cst, int B, int T, hipStream_t stream) {
+    if ((T & 3) || T < 8) return (int)hipErrorInvalidValue;
+    constexpr size_t lds = (size_t)2 * 32 * 257 * sizeof(float) + (size_t)3 * 32 * 72 * 2 + 128 * sizeof(float);
+    static bool done = false;
+    if (!done) {
+        WM_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_fwd_fused_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        WM_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_fwd_fused_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        done = true;
+    }
+    if (gates && cst) hipLaunchKernelGGL(lstm_fwd_fused_kernel<true>, dim3(B), dim3(256), lds, stream, x, w_ih, b_ih, b_hh, w_hh, hout, gates, cst, T);
+    else hipLaunchKernelGGL(lstm_fwd_fused_kernel<false>, dim3(B), dim3(256), lds, stream, x, w_ih, b_ih, b_hh, w_hh, hout, gates, cst, T);
     WM_CHECK_LAUNCH();
     return 0;
 }

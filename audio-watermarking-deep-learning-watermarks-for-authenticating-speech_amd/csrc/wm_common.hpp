@@ -100,4 +100,31 @@ __device__ __forceinline__ double block_sum_d(double v, double* scratch) {
 
 __device__ __forceinline__ float sigmoidf_acc(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+// ---- bf16x6 split arithmetic (see conv64.hip): x = hi + mid + lo as three bf16 pieces, exact to 24 bits
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+// two values -> three dwords, each holding the (a: low half, b: high half) pair of one piece
+__device__ __forceinline__ void split3_pair(float a, float b, unsigned& p0, unsigned& p1, unsigned& p2) {
+    bf16x2 h = {(__bf16)a, (__bf16)b};
+    p0 = __builtin_bit_cast(unsigned, h);
+    a -= __uint_as_float(p0 << 16); b -= __uint_as_float(p0 & 0xffff0000u);
+    bf16x2 m = {(__bf16)a, (__bf16)b};
+    p1 = __builtin_bit_cast(unsigned, m);
+    a -= __uint_as_float(p1 << 16); b -= __uint_as_float(p1 & 0xffff0000u);
+    bf16x2 l = {(__bf16)a, (__bf16)b};
+    p2 = __builtin_bit_cast(unsigned, l);
+}
+
+// acc += A*B to fp32 grade from the 3-piece fragments: the six piece products of weight >= 2^-16, small terms first
+__device__ __forceinline__ f32x16 mfma_bf16x6(const bf16x8 (&A)[3], const bf16x8 (&B)[3], f32x16 acc) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[1], B[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0], B[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[2], B[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0], B[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[1], B[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0], B[0], acc, 0, 0, 0);
+    return acc;
+}
+
 }  // namespace wm

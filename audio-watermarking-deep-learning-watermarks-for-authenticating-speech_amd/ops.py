@@ -316,6 +316,9 @@ class HeadNFn(torch.autograd.Function):
 
 
 # ------------------------------------------------------------------------------------------ LSTM
+_LSTM_FUSED = _os.environ.get("WM_LSTM_FUSED", "1") == "1"     # 0: separate wm_lstm_xproj + wm_lstm_fwd launches
+
+
 class LSTMFn(torch.autograd.Function):
     """nn.LSTM(64,64,batch_first=True) on channel-first frames: (B,64,T) -> (B,64,T); the two permutes of
     py/main16.py:152,154 are folded into the kernels' addressing."""
@@ -326,9 +329,18 @@ class LSTMFn(torch.autograd.Function):
         B, _, T = x.shape
         dev, st = x.device, _stream()
         need_grad = any(ctx.needs_input_grad)
+        h = torch.empty_like(x)
+        if _LSTM_FUSED and T >= 8:                 # input projection inside the recurrence kernel (no xp tensor)
+            gates = cst = None
+            if need_grad:
+                gates, cst = _f32(B, T, 256, device=dev), _f32(B, T, 64, device=dev)
+            lib.wm_lstm_fwd_fused(_p(x), _p(w_ih), _p(b_ih), _p(b_hh), _p(w_hh), _p(h), _p(gates), _p(cst), B, T, st)
+            if need_grad:
+                ctx.gdst = _gdst(w_ih, w_hh, b_ih, b_hh)
+                ctx.save_for_backward(x, h, gates, cst, w_ih, w_hh)
+            return h
         xp = _f32(B, T, 256, device=dev)
         lib.wm_lstm_xproj(_p(x), _p(w_ih), _p(b_ih), _p(b_hh), _p(xp), B, T, st)
-        h = torch.empty_like(x)
         if need_grad:
             gates, cst = xp, _f32(B, T, 64, device=dev)     # activations overwrite the projections in place
             lib.wm_lstm_fwd(_p(xp), _p(w_hh), _p(h), _p(gates), _p(cst), B, T, st)

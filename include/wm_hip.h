@@ -101,6 +101,11 @@ int wm_headN_bwd(const float* g, const float* x, const float* w, float* dx, floa
 int wm_lstm_xproj(const float* x, const float* w_ih, const float* b_ih, const float* b_hh, float* xp, int B, int T,
                   wm_stream_t stream);
 int wm_lstm_fwd(const float* xp, const float* w_hh, float* hout, float* gates, float* cst, int B, int T, wm_stream_t stream);
+/* xproj + recurrence in one launch: the projection of the next 32 steps runs on the bf16 matrix cores (bf16x6 split,
+ * fp32-grade) beside the recurrence and never touches HBM.  gates [B,T,256] / cst [B,T,64] (both or neither): saved
+ * activations / cell states for wm_lstm_bwd, exactly as wm_lstm_fwd writes them.  T >= 8. */
+int wm_lstm_fwd_fused(const float* x, const float* w_ih, const float* b_ih, const float* b_hh, const float* w_hh,
+                      float* hout, float* gates, float* cst, int B, int T, wm_stream_t stream);
 int wm_lstm_bwd(float* gates, const float* cst, const float* dh_out, const float* w_hh, int B, int T, wm_stream_t stream);
 int wm_lstm_dx(const float* da, const float* w_ih, float* dx, int B, int T, wm_stream_t stream);
 int wm_lstm_wgrad(const float* da, const float* x, const float* h, float* partial, float* dw_ih, float* dw_hh,
