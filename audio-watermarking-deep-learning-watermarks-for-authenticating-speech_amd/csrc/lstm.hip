@@ -18,6 +18,7 @@
 //   4. wm_lstm_dx / wm_lstm_wgrad   everything that is NOT sequential leaves the recurrence:
 //                        dx = da W_ih, dW_ih = da^T x, dW_hh = da^T h_{t-1}, db = sum da are MFMA GEMMs.
 #include "wm_common.hpp"
+#include <type_traits>
 using namespace wm;
 
 namespace {
@@ -284,18 +285,21 @@ __global__ __launch_bounds__(256) void lstm_fwd_fused_kernel(const float* __rest
     };
     f32x16 acc[2];
     bf16x8 Bf[NP];
-    // m-th block of 6 MFMAs of a chunk's projection: m = ks * 2 + mt
-    auto mfma_block = [&](int m) {
-        const int ks = m >> 1, mt = m & 1;
-        if (mt == 0) {
+    // idx-th of the 48 MFMAs of a chunk's projection: block m = idx / 6 = ks * 2 + mt, piece product idx % 6.  They are
+    // issued ONE at a time, far apart in the instruction stream: back-to-back dependent MFMAs would stall the wave's
+    // in-order issue (and with it the latency-bound recurrence) for the 32 cycles each one occupies the pipe.
+    auto mfma_one = [&](int idx) {
+        const int m = idx / 6, pr = idx % 6, ks = m >> 1, mt = m & 1;
+        const int pa = (pr == 0 || pr == 4) ? 1 : (pr == 2 ? 2 : 0), pb = (pr == 0 || pr == 3) ? 1 : (pr == 1 ? 2 : 0);
+        if (mt == 0 && pr == 0) {
 #pragma unroll
             for (int p = 0; p < NP; ++p) Bf[p] = *reinterpret_cast<const bf16x8*>(Xb + (p * CH + l31) * PITCH + 16 * ks + 8 * half);
         }
-        if (ks == 0) {
+        if (ks == 0 && pr == 0) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
         }
-        acc[mt] = mfma_bf16x6(Wi[mt][ks], Bf, acc[mt]);
+        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wi[mt][ks][pa], Bf[pb], acc[mt], 0, 0, 0);
     };
     auto store_xp = [&](int buf) {                 // D row = gate column (this wave's 64), D column = step
         float* dst = xps + (buf * CH + l31) * XPP + wave * 64 + 4 * half;
@@ -312,18 +316,22 @@ __global__ __launch_bounds__(256) void lstm_fwd_fused_kernel(const float* __rest
     load_x(CH);
     __syncthreads();
 #pragma unroll
-    for (int m = 0; m < 8; ++m) mfma_block(m);
+    for (int i = 0; i < 48; ++i) mfma_one(i);
     store_xp(0);
     __syncthreads();
 
     float hk[4];
-    for (int t0 = 0, cbuf = 0; t0 < T; t0 += CH, cbuf ^= 1) {
+    int t0 = 0, cbuf = 0;
+    // eight steps of the chunk with compile-time positions s = 8*SUB + j (register-array indices must be constants)
+    auto run8 = [&](auto sub_c) {
+        constexpr int SUB = decltype(sub_c)::value;
 #pragma unroll
-        for (int s = 0; s < CH; ++s) {
+        for (int j8 = 0; j8 < 8; ++j8) {
+            const int s = SUB * 8 + j8;
             const int t = t0 + s;
             // ---- side work: projection of the next chunk (independent of the recurrence; no effect past the end)
             if (s == 0) { split_x(); load_x(t0 + 2 * CH); }
-            if (s >= 2 && s < 26 && ((s - 2) % 3) == 0) mfma_block((s - 2) / 3);
+            if (s >= 2 && s < 26) mfma_one(2 * (s - 2));
             if (s == 28) store_xp(cbuf ^ 1);
             if (t < T) {                                   // uniform across the workgroup
                 const float xin = xps[(cbuf * CH + s) * XPP + np] + bias;
@@ -333,7 +341,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_fused_kernel(const float* __rest
                 float4 hq[(64 - HS) / 4];
 #pragma unroll
                 for (int k = 0; k < (64 - HS) / 4; ++k) hq[k] = hp[HS / 4 + k];
-                v2f a01 = v2f{xin, 0.f}, a23 = v2f{0.f, 0.f}, b01 = a23, b23 = a23;
+                v2f a01 = v2f{0.f, 0.f}, a23 = a01, b01 = a01, b23 = a01;     // xin joins at the end: its LDS read stays off the chain's head
 #pragma unroll
                 for (int k = 0; k < HS; k += 8) {
                     a01 = pk_fma_lanes(wr[k / 2], hv, k, a01);
@@ -349,8 +357,9 @@ __global__ __launch_bounds__(256) void lstm_fwd_fused_kernel(const float* __rest
                     b01 = __builtin_elementwise_fma(wr[HS / 2 + 2 * k + 2], v2f{h1.x, h1.y}, b01);
                     b23 = __builtin_elementwise_fma(wr[HS / 2 + 2 * k + 3], v2f{h1.z, h1.w}, b23);
                 }
+                if (s >= 2 && s < 26) mfma_one(2 * (s - 2) + 1);
                 const v2f sm = (a01 + a23) + (b01 + b23);
-                const float act = gate_act(sm.x + sm.y, is_g);
+                const float act = gate_act((sm.x + sm.y) + xin, is_g);
                 const float gi = quad_bcast<0>(act), gf = quad_bcast<1>(act), gg = quad_bcast<2>(act), go = quad_bcast<3>(act);
                 c = fmaf(gf, c, gi * gg);
                 const float h = go * tanh_s(c);
@@ -365,6 +374,12 @@ __global__ __launch_bounds__(256) void lstm_fwd_fused_kernel(const float* __rest
                 __syncthreads();
             }
         }
+    };
+    for (; t0 < T; t0 += CH, cbuf ^= 1) {
+        run8(std::integral_constant<int, 0>{});
+        run8(std::integral_constant<int, 1>{});
+        run8(std::integral_constant<int, 2>{});
+        run8(std::integral_constant<int, 3>{});
         // ragged tail (T % 16 != 0): flush what the last partial 16-step group produced
         if (t0 + CH > T && (T & 15)) {
             const int g0 = (T >> 4) << 4, tq0 = g0 + 4 * q;
@@ -467,6 +482,196 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(float* __restrict__ gates
         prefetch(A, t1 - 2 * CH);
         run_chunk(Bf, t1 - CH);
     }
+}
+
+// --------------------------------------------------- recurrence bwd with the input gradient inside
+// Same BPTT as lstm_bwd_kernel; in addition dx[b,c,t] = sum_n' w_ih[gate_row(n')][c] da[t][n'] is formed here instead of
+// in a separate GEMM over the 4.2-GB da tensor.  Every lane drops the three bf16 pieces of its da into a wave-private
+// LDS image [piece][step][gate column] as it produces it; one 32-step chunk later the wave multiplies that image with its
+// 64 rows of W_ih^T (A fragments resident in registers) on the bf16 matrix cores -- 48 MFMAs dealt two per step beside
+// the VALU recurrence -- and the four waves' partial [64 x 32] tiles are summed through LDS and stored as coalesced rows.
+__global__ __launch_bounds__(256) void lstm_bwd_fused_kernel(float* __restrict__ gates, const float* __restrict__ cst,
+                                                             const float* __restrict__ dh_out, const float* __restrict__ w_hh,
+                                                             const float* __restrict__ w_ih, float* __restrict__ dx, int T) {
+    constexpr int HS = WM_LSTM_HS, CHK = 32, PITCH = 72, NP = 3, PDP = 33;
+    constexpr int DIMG = NP * CHK * PITCH;                       // bf16 elements of one wave's image
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    unsigned short* Dab = reinterpret_cast<unsigned short*>(smem_raw);             // [2][4 waves][NP][CHK][PITCH]
+    float* Pd = reinterpret_cast<float*>(Dab + 2 * 4 * DIMG);                       // [4 waves][64][PDP]
+    float* das = Pd + 4 * 64 * PDP;                                                 // [4][64] wave-private da vectors
+    float* part = das + 4 * 64;                                                     // [2][64][4] partial dh
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const int q = lane & 3, ul = lane >> 2, u = wave * 16 + ul, np = wave * 64 + lane;
+    v2f wt[32];                                    // transposed W_hh operand: lane = output k, register j = gate row of lane j
+#pragma unroll
+    for (int j = 0; j < 64; j += 2)
+        wt[j / 2] = v2f{w_hh[((j & 3) * 64 + wave * 16 + (j >> 2)) * 64 + lane],
+                        w_hh[(((j + 1) & 3) * 64 + wave * 16 + ((j + 1) >> 2)) * 64 + lane]};
+    // W_ih^T A fragments: A[i = channel mt*32 + l31][k = this wave's gate column 16 ks + 8 half + j]
+    bf16x8 Wt[2][4][NP];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = w_ih[gate_row(wave * 64 + 16 * ks + 8 * half + j) * 64 + mt * 32 + l31];
+            unsigned a[4], m[4], l[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) split3_pair(v[2 * j], v[2 * j + 1], a[j], m[j], l[j]);
+            Wt[mt][ks][0] = __builtin_bit_cast(bf16x8, make_uint4(a[0], a[1], a[2], a[3]));
+            Wt[mt][ks][1] = __builtin_bit_cast(bf16x8, make_uint4(m[0], m[1], m[2], m[3]));
+            Wt[mt][ks][2] = __builtin_bit_cast(bf16x8, make_uint4(l[0], l[1], l[2], l[3]));
+        }
+    if (tid < 128) reinterpret_cast<float4*>(part)[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+    float dc = 0.f;
+    float* gb = gates + (size_t)b * T * 256 + np;
+    const float* cb = cst + (size_t)b * T * 64 + u;
+    const float* dhb = dh_out + ((size_t)b * 64 + u) * T;
+
+    constexpr int CH = 8;
+    struct Buf { float ga[CH], cc[CH + 1], dh[CH]; };
+    Buf A, Bf;
+    auto prefetch = [&](Buf& f, int t1) {          // steps t1-CH+1 .. t1; unconditional loads from clamped indices
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            const int t = max(t1 - CH + 1 + j, 0);
+            f.ga[j] = gb[(size_t)t * 256];
+            f.dh[j] = dhb[t];
+        }
+#pragma unroll
+        for (int j = 0; j <= CH; ++j) f.cc[j] = cb[(size_t)max(t1 - CH + j, 0) * 64];
+    };
+    f32x16 acc[2];
+    bf16x8 Bq[NP];
+    int ibuf = 0;                                  // image being filled by the current 32-step chunk
+    // idx-th of the 48 MFMAs of the previous chunk's product (block idx / 6 = ks*2 + mt, piece product idx % 6), issued one
+    // at a time and far apart: see lstm_fwd_fused_kernel
+    auto mfma_one = [&](int idx, int img) {
+        const int m = idx / 6, pr = idx % 6, ks = m >> 1, mt = m & 1;
+        const int pa = (pr == 0 || pr == 4) ? 1 : (pr == 2 ? 2 : 0), pbi = (pr == 0 || pr == 3) ? 1 : (pr == 1 ? 2 : 0);
+        const unsigned short* im = Dab + (img * 4 + wave) * DIMG;
+        if (mt == 0 && pr == 0) {
+#pragma unroll
+            for (int p = 0; p < NP; ++p) Bq[p] = *reinterpret_cast<const bf16x8*>(im + (p * CHK + l31) * PITCH + 16 * ks + 8 * half);
+        }
+        if (ks == 0 && pr == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+        }
+        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wt[mt][ks][pa], Bq[pbi], acc[mt], 0, 0, 0);
+    };
+    auto store_partial = [&]() {                   // D row = channel, D column = step of the chunk
+        float* dst = Pd + (wave * 64 + 4 * half) * PDP + l31;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dst[(mt * 32 + (r & 3) + 8 * (r >> 2)) * PDP] = acc[mt][r];
+    };
+    auto reduce_store = [&](int tlo) {             // thread -> channel tid>>2, 8 steps from 8*(tid&3)
+        const int ch = tid >> 2, j0 = 8 * (tid & 3);
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int i = ch * PDP + j0 + j;
+            o[j] = (Pd[i] + Pd[64 * PDP + i]) + (Pd[2 * 64 * PDP + i] + Pd[3 * 64 * PDP + i]);
+        }
+        float* dst = dx + ((size_t)b * 64 + ch) * T + tlo + j0;
+        if (tlo + j0 >= 0) *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+        if (tlo + j0 + 4 >= 0) *reinterpret_cast<float4*>(dst + 4) = make_float4(o[4], o[5], o[6], o[7]);
+    };
+    int pb = 0;   // partial buffer parity
+    int prev_tlo = 0;
+    bool have_prev = false;
+    // SUB = 8-step quarter of the 32-step chunk whose top step is t1 + 8*SUB
+    auto run_chunk = [&](const Buf& f, int t1, auto sub_c) {
+        constexpr int SUB = decltype(sub_c)::value;
+        unsigned short* myimg = Dab + (ibuf * 4 + wave) * DIMG;
+#pragma unroll
+        for (int jj = 0; jj < CH; ++jj) {
+            const int j = CH - 1 - jj, t = t1 - jj;
+            constexpr int dummy = 0; (void)dummy;
+            const int s32 = SUB * 8 + jj, tt = 31 - s32;   // position in the chunk: time = tlo + tt
+            // ---- side work for the previous chunk (its image is complete)
+            if (have_prev) {
+                if (s32 >= 2 && s32 < 26) mfma_one(2 * (s32 - 2), ibuf ^ 1);
+                if (s32 == 26) store_partial();
+                if (s32 == 27) { __syncthreads(); reduce_store(prev_tlo); }
+            }
+            if (t >= 0) {
+                const float4 p = *reinterpret_cast<const float4*>(part + (pb * 64 + u) * 4);
+                const float dht = f.dh[j] + ((p.x + p.y) + (p.z + p.w));
+                const float act = f.ga[j];
+                const float gi = quad_bcast<0>(act), gf = quad_bcast<1>(act), gg = quad_bcast<2>(act), go = quad_bcast<3>(act);
+                const float tc = tanh_s(f.cc[j + 1]);
+                const float cprev = (t >= 1) ? f.cc[j] : 0.f;
+                const float dct = fmaf(dht * go, 1.f - tc * tc, dc);
+                float da;
+                if (q == 0) da = dct * gg * gi * (1.f - gi);
+                else if (q == 1) da = dct * cprev * gf * (1.f - gf);
+                else if (q == 2) da = dct * gi * (1.f - gg * gg);
+                else da = dht * tc * go * (1.f - go);
+                dc = dct * gf;
+                gb[(size_t)t * 256] = da;
+                das[wave * 64 + lane] = da;                 // same wave reads it back: no barrier needed
+                __builtin_amdgcn_wave_barrier();
+                const float4* dp = reinterpret_cast<const float4*>(das + wave * 64);
+                float4 dq[(64 - HS) / 4];
+#pragma unroll
+                for (int k = 0; k < (64 - HS) / 4; ++k) dq[k] = dp[HS / 4 + k];
+                {   // under the latency of those reads: bf16 pieces of da for the dx product, [piece][step tt][gate column]
+                    unsigned p0, p1, p2;
+                    split3_pair(da, 0.f, p0, p1, p2);
+                    unsigned short* d = myimg + tt * PITCH + lane;
+                    d[0] = (unsigned short)p0; d[CHK * PITCH] = (unsigned short)p1; d[2 * CHK * PITCH] = (unsigned short)p2;
+                }
+                v2f a01 = v2f{0.f, 0.f}, a23 = a01;
+#pragma unroll
+                for (int k = 0; k < HS; k += 4) {
+                    a01 = pk_fma_lanes(wt[k / 2], da, k, a01);
+                    a23 = pk_fma_lanes(wt[k / 2 + 1], da, k + 2, a23);
+                }
+#pragma unroll
+                for (int k = 0; k < (64 - HS) / 4; ++k) {
+                    const float4 d = dq[k];
+                    a01 = __builtin_elementwise_fma(wt[HS / 2 + 2 * k], v2f{d.x, d.y}, a01);
+                    a23 = __builtin_elementwise_fma(wt[HS / 2 + 2 * k + 1], v2f{d.z, d.w}, a23);
+                }
+                const v2f sm = a01 + a23;
+                part[((pb ^ 1) * 64 + lane) * 4 + wave] = sm.x + sm.y;
+                pb ^= 1;
+                if (have_prev && s32 >= 2 && s32 < 26) mfma_one(2 * (s32 - 2) + 1, ibuf ^ 1);
+                __syncthreads();
+            } else {
+                // steps before the clip: zero pieces so that the partial last chunk multiplies zeros
+                unsigned short* d = myimg + tt * PITCH + lane;
+                d[0] = 0; d[CHK * PITCH] = 0; d[2 * CHK * PITCH] = 0;
+                if (have_prev && s32 >= 2 && s32 < 26) mfma_one(2 * (s32 - 2) + 1, ibuf ^ 1);
+            }
+        }
+    };
+    prefetch(A, T - 1);
+    __syncthreads();
+    for (int t1 = T - 1; t1 >= 0; t1 -= CHK) {
+        prefetch(Bf, t1 - CH);
+        run_chunk(A, t1, std::integral_constant<int, 0>{});
+        prefetch(A, t1 - 2 * CH);
+        run_chunk(Bf, t1 - CH, std::integral_constant<int, 1>{});
+        prefetch(Bf, t1 - 3 * CH);
+        run_chunk(A, t1 - 2 * CH, std::integral_constant<int, 2>{});
+        prefetch(A, t1 - 4 * CH);
+        run_chunk(Bf, t1 - 3 * CH, std::integral_constant<int, 3>{});
+        prev_tlo = t1 - (CHK - 1);
+        have_prev = true;
+        ibuf ^= 1;
+    }
+    // flush: the last chunk's product
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 48; ++i) mfma_one(i, ibuf ^ 1);
+    store_partial();
+    __syncthreads();
+    reduce_store(prev_tlo);
 }
 
 // ------------------------------------------------------------------------------------ dx GEMM
@@ -688,6 +893,21 @@ int wm_lstm_fwd_fused(const float* x, const float* w_ih, const float* b_ih, cons
 // gates: saved activations in, da out.  dh_out [B,64,T] = gradient w.r.t. hout.
 int wm_lstm_bwd(float* gates, const float* cst, const float* dh_out, const float* w_hh, int B, int T, hipStream_t stream) {
     hipLaunchKernelGGL(lstm_bwd_kernel, dim3(B), dim3(256), 0, stream, gates, cst, dh_out, w_hh, T);
+    WM_CHECK_LAUNCH();
+    return 0;
+}
+
+// BPTT + input gradient in one launch (no separate pass over da for dx): gates in = saved activations, out = da.
+int wm_lstm_bwd_fused(float* gates, const float* cst, const float* dh_out, const float* w_hh, const float* w_ih, float* dx,
+                      int B, int T, hipStream_t stream) {
+    if ((T & 3) || T < 4) return (int)hipErrorInvalidValue;
+    constexpr size_t lds = (size_t)2 * 4 * 3 * 32 * 72 * 2 + (size_t)(4 * 64 * 33 + 4 * 64 + 2 * 64 * 4) * sizeof(float);
+    static bool done = false;
+    if (!done) {
+        WM_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_bwd_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        done = true;
+    }
+    hipLaunchKernelGGL(lstm_bwd_fused_kernel, dim3(B), dim3(256), lds, stream, gates, cst, dh_out, w_hh, w_ih, dx, T);
     WM_CHECK_LAUNCH();
     return 0;
 }

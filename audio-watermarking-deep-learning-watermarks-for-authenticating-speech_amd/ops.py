@@ -317,6 +317,7 @@ class HeadNFn(torch.autograd.Function):
 
 # ------------------------------------------------------------------------------------------ LSTM
 _LSTM_FUSED = _os.environ.get("WM_LSTM_FUSED", "1") == "1"     # 0: separate wm_lstm_xproj + wm_lstm_fwd launches
+_LSTM_BWD_FUSED = _os.environ.get("WM_LSTM_BWD_FUSED", "0") == "1"   # 1: wm_lstm_bwd + wm_lstm_dx as one launch
 
 
 class LSTMFn(torch.autograd.Function):
@@ -356,9 +357,12 @@ class LSTMFn(torch.autograd.Function):
         dh = dh.contiguous()
         B, _, T = x.shape
         dev, st = x.device, _stream()
-        lib.wm_lstm_bwd(_p(gates), _p(cst), _p(dh), _p(w_hh), B, T, st)          # gates now holds da
         dx = torch.empty_like(x)
-        lib.wm_lstm_dx(_p(gates), _p(w_ih), _p(dx), B, T, st)
+        if _LSTM_BWD_FUSED:                        # measured: no faster than the two launches; off by default
+            lib.wm_lstm_bwd_fused(_p(gates), _p(cst), _p(dh), _p(w_hh), _p(w_ih), _p(dx), B, T, st)   # gates now holds da
+        else:
+            lib.wm_lstm_bwd(_p(gates), _p(cst), _p(dh), _p(w_hh), B, T, st)      # gates now holds da
+            lib.wm_lstm_dx(_p(gates), _p(w_ih), _p(dx), B, T, st)
         side = all(g is not None for g in ctx.gdst)
         if side:
             gwi, gwh, gbi, gbh = ctx.gdst

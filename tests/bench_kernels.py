@@ -80,6 +80,7 @@ gt = _f32(B, T, 256, device=dev)
 timeit("lstm fused fwd (save)", lambda: lib.wm_lstm_fwd_fused(_p(x), _p(wi), _p(bi), _p(bi), _p(wh), _p(h), _p(gt), _p(cst), B, T, st), None, None, n=2)
 timeit("lstm fused fwd (inference)", lambda: lib.wm_lstm_fwd_fused(_p(x), _p(wi), _p(bi), _p(bi), _p(wh), _p(h), None, None, B, T, st), None, None, n=2)
 timeit("lstm_bwd (on stale gates)", lambda: lib.wm_lstm_bwd(_p(xp), _p(cst), _p(x2), _p(wh), B, T, st), None, None, n=2)
+timeit("lstm bwd fused (+dx)", lambda: lib.wm_lstm_bwd_fused(_p(xp), _p(cst), _p(x2), _p(wh), _p(wi), _p(y), B, T, st), None, None, n=2)
 timeit("lstm_dx", lambda: lib.wm_lstm_dx(_p(xp), _p(wi), _p(y), B, T, st), FL, 5 * FR, n=3)
 lpart = _f32(256 * (256 * 128 + 256), device=dev); dwi = torch.empty_like(wi); dwh = torch.empty_like(wh); dbi = _f32(256, device=dev); dbh = _f32(256, device=dev)
 timeit("lstm_wgrad", lambda: lib.wm_lstm_wgrad(_p(xp), _p(x), _p(h), _p(lpart), _p(dwi), _p(dwh), _p(dbi), _p(dbh), B, T, 0, st), 2 * FL, 6 * FR, n=3)

@@ -229,6 +229,35 @@ def test_lstm_small(awm, dev, B, T):
     check(bhd.grad, bhr.grad, GRAD_TOL, "lstm db_hh")
 
 
+@pytest.mark.parametrize("fwd_fused,bwd_fused", [(False, False), (True, True), (False, True)])
+@pytest.mark.parametrize("B,T", [(2, 200), (1, 36)])
+def test_lstm_launch_variants(awm, dev, monkeypatch, fwd_fused, bwd_fused, B, T):
+    """every C-ABI route through the LSTM (wm_lstm_xproj + wm_lstm_fwd | wm_lstm_fwd_fused; wm_lstm_bwd + wm_lstm_dx |
+    wm_lstm_bwd_fused) against the oracle, on lengths that leave ragged 32-step chunks and 16-step groups"""
+    from awm_amd import ops
+    monkeypatch.setattr(ops, "_LSTM_FUSED", fwd_fused)
+    monkeypatch.setattr(ops, "_LSTM_BWD_FUSED", bwd_fused)
+    g = torch.Generator().manual_seed(40)
+    k = 1.0 / 8.0
+    wi, wh = (torch.rand(256, 64, generator=g) * 2 - 1) * k, (torch.rand(256, 64, generator=g) * 2 - 1) * k
+    bi, bh = (torch.rand(256, generator=g) * 2 - 1) * k, (torch.rand(256, generator=g) * 2 - 1) * k
+    x = rnd(B, 64, T, seed=41)
+    xr, wir, whr, bir, bhr = (t.clone().requires_grad_() for t in (x, wi, wh, bi, bh))
+    hr = O.lstm_forward(xr.permute(0, 2, 1), wir, whr, bir, bhr).permute(0, 2, 1)
+    gg = rnd(B, 64, T, seed=42)
+    hr.backward(gg)
+    xd, wid, whd, bid, bhd = (t.to(dev).requires_grad_() for t in (x, wi, wh, bi, bh))
+    h = ops.LSTMFn.apply(xd, wid, whd, bid, bhd)
+    check(h, hr, FWD_TOL, "lstm fwd")
+    with torch.no_grad():
+        check(ops.LSTMFn.apply(x.to(dev), wid.detach(), whd.detach(), bid.detach(), bhd.detach()), hr, FWD_TOL, "lstm fwd (inference)")
+    h.backward(gg.to(dev))
+    check(xd.grad, xr.grad, GRAD_TOL, "lstm dx")
+    check(wid.grad, wir.grad, GRAD_TOL, "lstm dW_ih")
+    check(whd.grad, whr.grad, GRAD_TOL, "lstm dW_hh")
+    check(bid.grad, bir.grad, GRAD_TOL, "lstm db_ih")
+
+
 def test_lstm_long_horizon(awm, dev):
     """all 16000 dependent steps (SURVEY.md hard part 1): drift must stay inside 1e-4"""
     from awm_amd import ops
