@@ -1350,6 +1350,183 @@ int launch_conv64bf2(const Conv64Args& a, hipStream_t stream) {
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------
+// bf16x6 build of the 7-tap convolution (Generator.decoder[0] = ConvTranspose1d(64,64,7,padding=3), py/main16.py:144,
+// forward and data gradient).  The 3-piece image of all 7 taps is 194 KB -- more than LDS -- so a workgroup keeps the
+// taps of HALF the output channels (97 KB) and the (tile, half) pairs are dealt over the grid: workgroup g owns half
+// g & 1 for its whole life.  The input tile is read by two workgroups (8 MB/clip extra on a kernel that moves 8 MB per
+// 918 MFLOP: still far from HBM-bound); each of the four waves owns 32 columns of the 32 x 128 output tile.
+// ---------------------------------------------------------------------------------------------
+template <int PRO, int EPI>
+__global__ __launch_bounds__(256) void conv64bf7_kernel(Conv64Args a) {
+    constexpr int KW = 7, PAD = 3, NT = 128, ROWS = NT + 2 * PAD, PITCH = 72, NP = 3, NC = 4, MR = 32;
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    unsigned short* Wb = reinterpret_cast<unsigned short*>(smem_raw);              // [NP][KW][MR][PITCH]
+    unsigned short* Xb = Wb + NP * KW * MR * PITCH;                                // [NP][ROWS][PITCH]
+    float* Cs = reinterpret_cast<float*>(Xb + NP * ROWS * PITCH);                  // [32] bias of this half
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const int mh = blockIdx.x & 1, nslots = gridDim.x >> 1;                        // gridDim.x is even
+    const int T = a.T;
+    const int tilesPerClip = (T + NT - 1) / NT, ntiles = a.B * tilesPerClip;
+
+    float4 sa[NC], sb[NC];
+    float hl[2];
+    float pv0[NC], pv1[NC], hv[2];                // ADDVEC: the clip's embedding values, prefetched with the tile (a load
+                                                  // inside write_tile would put a global round trip into the serial phase)
+    auto combo = [&](int i, int& cp, int& q) {
+        const int idx = tid + i * 256, widx = idx >> 6, l = idx & 63;
+        cp = (widx & 3) * 8 + (l & 7);
+        q = (widx >> 2) * 8 + (l >> 3);
+    };
+    auto halo_of = [&](int k, int t0, int& c, int& r, int& t) {                    // k-th halo element of this thread
+        const int idx = min(tid + k * 256, 64 * 2 * PAD - 1);
+        c = idx / (2 * PAD);
+        const int h = idx % (2 * PAD);
+        r = (h < PAD) ? h : NT + h;                                                 // image row: time = t0 - PAD + r
+        t = t0 - PAD + r;
+    };
+    // piece i < NC: one staging combo; piece NC: the halo.  Branch-free (clamped addresses, masked at the LDS write); the
+    // main loop issues one piece per tap so that the tile's loads never arrive at the memory pipeline as one burst
+    auto load_piece = [&](int tile, int i) {
+        const int b = tile / tilesPerClip, t0 = (tile - b * tilesPerClip) * NT;
+        const float* xb = a.x + (size_t)b * 64 * T;
+        if (i < NC) {
+            int cp, q;
+            combo(i, cp, q);
+            const size_t o = (size_t)(2 * cp) * T + min(t0 + 4 * q, T - 4);
+            sa[i] = *reinterpret_cast<const float4*>(xb + o);
+            sb[i] = *reinterpret_cast<const float4*>(xb + o + T);
+            if (PRO == PRO_ADDVEC) { pv0[i] = a.pa[b * 64 + 2 * cp]; pv1[i] = a.pa[b * 64 + 2 * cp + 1]; }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                int c, r, t;
+                halo_of(k, t0, c, r, t);
+                hl[k] = xb[(size_t)c * T + min(max(t, 0), T - 1)];
+                if (PRO == PRO_ADDVEC) hv[k] = a.pa[b * 64 + c];
+            }
+        }
+    };
+    auto load_tile = [&](int tile) {
+#pragma unroll
+        for (int i = 0; i <= NC; ++i) load_piece(tile, i);
+    };
+    auto write_tile = [&](int tile) {
+        const int b = tile / tilesPerClip, t0 = (tile - b * tilesPerClip) * NT;
+        unsigned* X32 = reinterpret_cast<unsigned*>(Xb);
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            int cp, q;
+            combo(i, cp, q);
+            const int c = 2 * cp, t = t0 + 4 * q;
+            float va[4] = {sa[i].x, sa[i].y, sa[i].z, sa[i].w}, vb[4] = {sb[i].x, sb[i].y, sb[i].z, sb[i].w};
+            if (PRO == PRO_ADDVEC) {
+                const float v0 = pv0[i], v1 = pv1[i];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { va[e] += v0; vb[e] += v1; }
+            }
+            const bool ok = t < T;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                unsigned p0, p1, p2;
+                split3_pair(ok ? va[e] : 0.f, ok ? vb[e] : 0.f, p0, p1, p2);
+                const int o = ((PAD + 4 * q + e) * PITCH + c) >> 1;
+                X32[o] = p0; X32[(ROWS * PITCH >> 1) + o] = p1; X32[2 * (ROWS * PITCH >> 1) + o] = p2;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            if (tid + k * 256 < 64 * 2 * PAD) {
+                int c, r, t;
+                halo_of(k, t0, c, r, t);
+                float v = hl[k];
+                if (PRO == PRO_ADDVEC) v += hv[k];
+                if (t < 0 || t >= T) v = 0.f;
+                unsigned p0, p1, p2;
+                split3_pair(v, 0.f, p0, p1, p2);
+                const int o = r * PITCH + c;
+                Xb[o] = (unsigned short)p0; Xb[ROWS * PITCH + o] = (unsigned short)p1; Xb[2 * ROWS * PITCH + o] = (unsigned short)p2;
+            }
+        }
+    };
+
+    int tile = blockIdx.x >> 1;
+    if (tile < ntiles) load_tile(tile);
+    // resident weights of this half: global image [NP][KW][64 out][64 in] bf16 -> LDS [NP][KW][32][PITCH]
+    for (int i = tid; i < NP * KW * MR * 8; i += 256) {
+        const int row = i >> 3, seg = i & 7, pt = row / MR, o = row % MR;
+        *reinterpret_cast<uint4*>(Wb + row * PITCH + seg * 8) = reinterpret_cast<const uint4*>(a.wp)[(pt * 64 + mh * MR + o) * 8 + seg];
+    }
+    if (tid < MR) Cs[tid] = (EPI == EPI_BIAS && a.bias) ? a.bias[mh * MR + tid] : 0.f;
+    __syncthreads();
+    if (tile < ntiles) write_tile(tile);
+    __syncthreads();
+
+    while (tile < ntiles) {
+        const int next = tile + nslots, nextc = min(next, ntiles - 1);   // clamped: loaded (valid memory) but never written
+        const int b = tile / tilesPerClip, t0 = (tile - b * tilesPerClip) * NT;
+        const int tcol = t0 + wave * 32 + l31;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const unsigned short* wbase = Wb + l31 * PITCH + 8 * half;
+        const unsigned short* xbase = Xb + (wave * 32 + l31) * PITCH + 8 * half;
+#pragma unroll
+        for (int tap = 0; tap < KW; ++tap) {
+            if (tap >= 1 && tap <= NC + 1) load_piece(nextc, tap - 1);
+#pragma unroll
+            for (int ch = 0; ch < 4; ++ch) {
+                bf16x8 A[NP], Bf[NP];
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    Bf[p] = *reinterpret_cast<const bf16x8*>(xbase + (p * ROWS + tap) * PITCH + 16 * ch);
+                    A[p] = *reinterpret_cast<const bf16x8*>(wbase + ((p * KW + tap) * MR) * PITCH + 16 * ch);
+                }
+                acc = mfma_bf16x6(A, Bf, acc);
+            }
+        }
+        float* yb = a.y + ((size_t)b * 64 + mh * MR) * T + tcol;
+        if (tcol < T) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = mfma_row(r, half);
+                yb[(size_t)row * T] = acc[r] + Cs[row];
+            }
+        }
+        __syncthreads();
+        if (next < ntiles) write_tile(next);
+        __syncthreads();
+        tile = next;
+    }
+}
+
+template <int PRO, int EPI>
+int launch_conv64bf7(const Conv64Args& a, hipStream_t stream) {
+    constexpr size_t lds = (size_t)(3 * 7 * 32 * 72 + 3 * 134 * 72) * 2 + 32 * sizeof(float);
+    static bool attr_done = false;
+    auto kern = conv64bf7_kernel<PRO, EPI>;
+    if (!attr_done) {
+        WM_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    const int ntiles = a.B * ((a.T + 127) / 128);
+    const int grid = 2 * (ntiles < kNumCU / 2 ? ntiles : kNumCU / 2);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, a);
+    WM_CHECK_LAUNCH();
+    return 0;
+}
+
+// bf16 three-piece image [piece][tap][out][in] of a 7-tap ConvTranspose1d weight w[in][out][7]: mode 2 forward, 3 dgrad
+__global__ void pack_w64_bf7_kernel(const float* __restrict__ w, unsigned short* __restrict__ wpb, int mode) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 7 * 4096) return;
+    const int tap = i / 4096, out = (i / 64) % 64, in = i % 64;
+    const float v = (mode == 2) ? w[(in * 64 + out) * 7 + (6 - tap)] : w[(out * 64 + in) * 7 + tap];
+    unsigned p0, p1, p2;
+    split3_pair(v, 0.f, p0, p1, p2);
+    wpb[i] = (unsigned short)p0; wpb[7 * 4096 + i] = (unsigned short)p1; wpb[2 * 7 * 4096 + i] = (unsigned short)p2;
+}
+
 // bf16 three-piece weight image [piece][tap][out][in] (uint16) for the k3 convolutions; mode as wm_pack_w64 (0 / 1)
 __global__ void pack_w64_bf_kernel(const float* __restrict__ w, unsigned short* __restrict__ wpb, int mode) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1661,6 +1838,23 @@ int wm_conv64_bf(const float* x, const float* x2, const void* wpb, const float* 
     if (pro == PRO_BNBWD && epi == EPI_RELUMASK && st) return launch_conv64bf<PRO_BNBWD, EPI_RELUMASK, true>(a, stream);
     if (pro == PRO_BNBWD && epi == EPI_ADD && !st) return launch_conv64bf<PRO_BNBWD, EPI_ADD, false>(a, stream);
     if (pro == PRO_BNBWD && epi == EPI_NONE && !st) return launch_conv64bf<PRO_BNBWD, EPI_NONE, false>(a, stream);
+    return (int)hipErrorInvalidValue;
+}
+
+// bf16x6 build of the 7-tap ConvTranspose1d (forward: mode 2 image, pro 0|2, epi 0; data gradient: mode 3 image, pro 0, epi 3)
+int wm_pack_w64_bf7(const float* w, void* wpb, int mode, hipStream_t stream) {
+    if (mode != 2 && mode != 3) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(pack_w64_bf7_kernel, dim3((7 * 4096 + 255) / 256), dim3(256), 0, stream, w, reinterpret_cast<unsigned short*>(wpb), mode);
+    WM_CHECK_LAUNCH();
+    return 0;
+}
+int wm_conv64_bf7(const float* x, const void* wpb, const float* vec, const float* bias, float* y, int B, int T, int pro, int epi,
+                  hipStream_t stream) {
+    if (B <= 0 || T <= 0 || (T & 3)) return (int)hipErrorInvalidValue;
+    Conv64Args a{x, nullptr, reinterpret_cast<const float*>(wpb), vec, nullptr, nullptr, bias, nullptr, nullptr, nullptr, y, nullptr, B, T};
+    if (pro == PRO_NONE && epi == EPI_BIAS) return launch_conv64bf7<PRO_NONE, EPI_BIAS>(a, stream);
+    if (pro == PRO_ADDVEC && epi == EPI_BIAS) return launch_conv64bf7<PRO_ADDVEC, EPI_BIAS>(a, stream);
+    if (pro == PRO_NONE && epi == EPI_NONE) return launch_conv64bf7<PRO_NONE, EPI_NONE>(a, stream);
     return (int)hipErrorInvalidValue;
 }
 

@@ -124,6 +124,12 @@ def pack_w64_bf(w: torch.Tensor, mode: int) -> torch.Tensor:
     return wpb
 
 
+def pack_w64_bf7(w: torch.Tensor, mode: int) -> torch.Tensor:
+    wpb = torch.empty(3 * 7 * 4096, dtype=torch.int16, device=w.device)
+    lib.wm_pack_w64_bf7(_p(w), _p(wpb), mode, _stream())
+    return wpb
+
+
 def _conv3(x, x2, w, mode, pa, pb, pc, bias, e1, ea, eb, y, stats, B, T, pro, epi):
     """one k3 64->64 convolution launch in the selected arithmetic mode (mode: 0 forward, 1 data gradient)"""
     if _CONV["bf16x6"]:
@@ -410,10 +416,13 @@ class ConvT7Fn(torch.autograd.Function):
     def forward(ctx, x, vec, w, b):
         x = _frames(x, "decoder input", 64)
         B, _, T = x.shape
-        wp = pack_w64(w, 7, 2)
         y = torch.empty_like(x)
         pro = 2 if vec is not None else 0
-        lib.wm_conv64(_p(x), None, _p(wp), _p(vec), None, None, _p(b), None, None, None, _p(y), None, B, T, 7, pro, 0, _stream())
+        if _CONV["bf16x6"]:
+            lib.wm_conv64_bf7(_p(x), _p(pack_w64_bf7(w, 2)), _p(vec), _p(b), _p(y), B, T, pro, 0, _stream())
+        else:
+            lib.wm_conv64(_p(x), None, _p(pack_w64(w, 7, 2)), _p(vec), None, None, _p(b), None, None, None, _p(y), None, B, T, 7, pro, 0,
+                          _stream())
         ctx.has_vec = vec is not None
         ctx.gdst = _gdst(w, b)
         ctx.save_for_backward(x, w, vec if vec is not None else x.new_empty(0))
@@ -426,9 +435,11 @@ class ConvT7Fn(torch.autograd.Function):
         g = g.contiguous()
         B, _, T = x.shape
         dev, st = x.device, _stream()
-        wpd = pack_w64(w, 7, 3)
         dx = torch.empty_like(x)
-        lib.wm_conv64(_p(g), None, _p(wpd), None, None, None, None, None, None, None, _p(dx), None, B, T, 7, 0, 3, st)
+        if _CONV["bf16x6"]:
+            lib.wm_conv64_bf7(_p(g), _p(pack_w64_bf7(w, 3)), None, None, _p(dx), B, T, 0, 3, st)
+        else:
+            lib.wm_conv64(_p(g), None, _p(pack_w64(w, 7, 3)), None, None, None, None, None, None, None, _p(dx), None, B, T, 7, 0, 3, st)
         gw, gbias = ctx.gdst
         side = gw is not None and gbias is not None
 

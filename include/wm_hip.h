@@ -58,6 +58,12 @@ int wm_conv64_bf(const float* x, const float* x2, const void* wpb, const float* 
                  const float* bias, const float* e1, const float* ea, const float* eb, float* y, float* stats,
                  int B, int T, int pro, int epi, wm_stream_t stream);
 
+/* bf16x6 build of the 7-tap ConvTranspose1d(64,64,7,padding=3) (py/main16.py:144): wpb [3][7][64][64] uint16 from
+ * wm_pack_w64_bf7 (mode 2 forward | 3 data gradient).  pro 0 x | 2 x + vec[b*64+c]; epi 0 + bias[c] | 3 none. */
+int wm_pack_w64_bf7(const float* w, void* wpb, int mode, wm_stream_t stream);
+int wm_conv64_bf7(const float* x, const void* wpb, const float* vec, const float* bias, float* y, int B, int T, int pro, int epi,
+                  wm_stream_t stream);
+
 /* bf16x6 build of the k3 Conv1d weight gradient (contract of wm_wgrad64 with KW = 3, layout 0) */
 int wm_wgrad64_bf(const float* g, const float* g2, const float* ga, const float* gb, const float* gc,
                   const float* x, const float* xa, const float* xb, float* partial, float* dw, float* dbias,

@@ -57,6 +57,9 @@ if not only or "acc" in only:
     sc = float(ref.abs().max())
     print(f"acc vs fp64 (max abs / max|ref|): native fp32 MFMA {float((y1_.double().cpu()-ref).abs().max())/sc:.2e}   bf16x6 {float((y2_.double().cpu()-ref).abs().max())/sc:.2e}   torch CPU fp32 {float((cpu32.double()-ref).abs().max())/sc:.2e}")
 timeit("conv64 k7 fwd addvec/bias", lambda: lib.wm_conv64(_p(x), None, _p(wp7), _p(vec), None, None, _p(bias), None, None, None, _p(y), None, B, T, 7, 2, 0, st), F7, 2 * FR)
+wpb7 = ops.pack_w64_bf7(w7, 2)
+timeit("conv64bf7 k7 fwd addvec/bias", lambda: lib.wm_conv64_bf7(_p(x), _p(wpb7), _p(vec), _p(bias), _p(y), B, T, 2, 0, st), F7, 2 * FR)
+timeit("conv64bf7 k7 dgrad none/none", lambda: lib.wm_conv64_bf7(_p(x), _p(wpb7), None, None, _p(y), B, T, 0, 3, st), F7, 2 * FR)
 timeit("conv64 k7 dgrad none/none", lambda: lib.wm_conv64(_p(x), None, _p(wp7), None, None, None, None, None, None, None, _p(y), None, B, T, 7, 0, 3, st), F7, 2 * FR)
 timeit("wgrad64 k3 bnbwd x bnrelu", lambda: lib.wm_wgrad64(_p(x), _p(x2), _p(c[0]), _p(c[1]), _p(c[2]), _p(x3), _p(c[3]), _p(c[4]), _p(wpart), _p(dw3), _p(db), B, T, 3, 3, 1, 0, 0, st), F3, 3 * FR)
 timeit("wgrad64 k3 bnbwd x none", lambda: lib.wm_wgrad64(_p(x), _p(x2), _p(c[0]), _p(c[1]), _p(c[2]), _p(x3), None, None, _p(wpart), _p(dw3), _p(db), B, T, 3, 3, 0, 0, 0, st), F3, 3 * FR)
