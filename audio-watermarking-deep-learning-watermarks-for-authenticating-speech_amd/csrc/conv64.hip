@@ -1750,6 +1750,184 @@ int launch_wgrad64bf(const Wgrad64Args& a, int* grid_out, hipStream_t stream) {
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------
+// bf16x6 weight gradient of the 7-tap ConvTranspose1d: G[tap][out][in] = sum_t g[out][t] x[in][t + tap - 3].
+// Same LDS scheme as wgrad64bf_kernel ([channel][time] 3-piece images, fragments = aligned ds_read_b128 along time).
+// Wave (nt, kh) owns the 32 input-channel columns nt and half kh of the tile's time range for ALL seven taps and both
+// output halves (224 accumulator registers): per 16-step k-block it reads one 24-element window per piece and builds
+// the seven shifted B fragments from it in registers (dword selects for even shifts, v_alignbit for odd ones), so the
+// matrix phase needs 15 LDS reads per 84 MFMAs.  The two time halves meet in the final slab reduction.
+// ---------------------------------------------------------------------------------------------
+template <int XPRO>
+__global__ __launch_bounds__(256) void wgrad64bf7_kernel(Wgrad64Args a) {
+    constexpr int KW = 7, PAD = 3, NT = 128, NP = 3, PG = 136, PX = 152, XO = 8;
+    constexpr int QR = NT / 4, NV = 64 * QR / 256;
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    unsigned short* Gb = reinterpret_cast<unsigned short*>(smem_raw);          // [NP][64][PG]
+    unsigned short* Xb = Gb + NP * 64 * PG;                                    // [NP][64][PX]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const int nt = wave & 1, mt = wave >> 1;           // this wave's 32 x 32 block of every tap's [out][in] matrix
+    const int T = a.T;
+    const int tilesPerClip = (T + NT - 1) / NT, ntiles = a.B * tilesPerClip;
+    const int c0 = tid >> 5, q = tid & 31;             // staging: rows c0 + 8 i, float4 column q
+
+    float4 sg[NV], sx[NV];
+    float xv[NV], hx[2], hv[2];
+    float bsum[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) bsum[i] = 0.f;
+
+    auto halo_of = [&](int k, int t0, int& c, int& e, int& t) {   // k-th halo element of this thread: channel, image element, time
+        const int idx = min(tid + k * 256, 64 * 2 * PAD - 1);
+        c = idx / (2 * PAD);
+        const int h = idx % (2 * PAD);
+        e = (h < PAD) ? XO - PAD + h : XO + NT + (h - PAD);
+        t = t0 + e - XO;
+    };
+    auto load_piece = [&](int tile, int i) {        // branch-free (clamped addresses); piece NV = halo
+        const int b = tile / tilesPerClip, t0 = (tile - b * tilesPerClip) * NT;
+        const size_t base = (size_t)b * 64 * T;
+        if (i < NV) {
+            const int c = c0 + 8 * i, t = min(t0 + 4 * q, T - 4);
+            sg[i] = *reinterpret_cast<const float4*>(a.g + base + (size_t)c * T + t);
+            sx[i] = *reinterpret_cast<const float4*>(a.x + base + (size_t)c * T + t);
+            if (XPRO == PRO_ADDVEC) xv[i] = a.xa[b * 64 + c];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                int c, e, t;
+                halo_of(k, t0, c, e, t);
+                hx[k] = a.x[base + (size_t)c * T + min(max(t, 0), T - 1)];
+                if (XPRO == PRO_ADDVEC) hv[k] = a.xa[b * 64 + c];
+            }
+        }
+    };
+    auto put4 = [&](unsigned short* dst, int stride_p, float v0, float v1, float v2, float v3) {
+        unsigned a0, a1, a2, b0, b1, b2;
+        split3_pair(v0, v1, a0, a1, a2);
+        split3_pair(v2, v3, b0, b1, b2);
+        *reinterpret_cast<uint2*>(dst) = make_uint2(a0, b0);
+        *reinterpret_cast<uint2*>(dst + stride_p) = make_uint2(a1, b1);
+        *reinterpret_cast<uint2*>(dst + 2 * stride_p) = make_uint2(a2, b2);
+    };
+    auto write_tile = [&](int tile) {
+        const int t0 = (tile % tilesPerClip) * NT;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = c0 + 8 * i, t = t0 + 4 * q;
+            float4 v = sg[i], u = sx[i];
+            if (XPRO == PRO_ADDVEC) { u.x += xv[i]; u.y += xv[i]; u.z += xv[i]; u.w += xv[i]; }
+            if (t >= T) { v = make_float4(0.f, 0.f, 0.f, 0.f); u = v; }
+            bsum[i] += (v.x + v.y) + (v.z + v.w);
+            put4(Gb + c * PG + 4 * q, 64 * PG, v.x, v.y, v.z, v.w);
+            put4(Xb + c * PX + XO + 4 * q, 64 * PX, u.x, u.y, u.z, u.w);
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            if (tid + k * 256 < 64 * 2 * PAD) {
+                int c, e, t;
+                halo_of(k, t0, c, e, t);
+                float v = hx[k];
+                if (XPRO == PRO_ADDVEC) v += hv[k];
+                if (t < 0 || t >= T) v = 0.f;
+                unsigned p0, p1, p2;
+                split3_pair(v, 0.f, p0, p1, p2);
+                const int o = c * PX + e;
+                Xb[o] = (unsigned short)p0; Xb[64 * PX + o] = (unsigned short)p1; Xb[2 * 64 * PX + o] = (unsigned short)p2;
+            }
+        }
+    };
+
+    int tile = WM_XCD_MAP ? xcd_slot() : (int)blockIdx.x;          // grid <= ntiles
+#pragma unroll
+    for (int i = 0; i <= NV; ++i) load_piece(tile, i);
+    // window elements outside [XO - 3, XO + NT + 3) are read but never reach an MFMA: give them a defined value once
+    for (int i = tid; i < NP * 64 * PX; i += 256) Xb[i] = 0;
+    __syncthreads();
+    write_tile(tile);
+    __syncthreads();
+
+    f32x16 acc[KW];
+#pragma unroll
+    for (int k = 0; k < KW; ++k)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
+
+    while (tile < ntiles) {
+        const int next = tile + gridDim.x;
+        const int nextc = min(next, ntiles - 1);         // clamped: loaded (valid memory) but never written
+#pragma unroll
+        for (int kb = 0; kb < 8; ++kb) {                 // the tile's 128 time steps = 8 k-blocks of 16
+            const int e0 = kb * 16 + 8 * half;
+            bf16x8 A[NP];
+            unsigned W[NP][12];
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                A[p] = *reinterpret_cast<const bf16x8*>(Gb + (p * 64 + mt * 32 + l31) * PG + e0);
+                const unsigned short* xr = Xb + (p * 64 + nt * 32 + l31) * PX + XO + e0;
+                const uint4 w0 = *reinterpret_cast<const uint4*>(xr - 8), w1 = *reinterpret_cast<const uint4*>(xr),
+                            w2 = *reinterpret_cast<const uint4*>(xr + 8);
+                W[p][0] = w0.x; W[p][1] = w0.y; W[p][2] = w0.z; W[p][3] = w0.w;
+                W[p][4] = w1.x; W[p][5] = w1.y; W[p][6] = w1.z; W[p][7] = w1.w;
+                W[p][8] = w2.x; W[p][9] = w2.y; W[p][10] = w2.z; W[p][11] = w2.w;
+            }
+#pragma unroll
+            for (int tap = 0; tap < KW; ++tap) {
+                // fragment = 8 elements from window element 8 + (tap - PAD): dword d0, odd start -> funnel shift
+                constexpr int dummy = 0; (void)dummy;
+                const int st = 8 + tap - PAD, d0 = st >> 1;
+                bf16x8 Bt[NP];
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    uint4 f;
+                    if (st & 1)
+                        f = make_uint4(__builtin_amdgcn_alignbit(W[p][d0 + 1], W[p][d0], 16), __builtin_amdgcn_alignbit(W[p][d0 + 2], W[p][d0 + 1], 16),
+                                       __builtin_amdgcn_alignbit(W[p][d0 + 3], W[p][d0 + 2], 16), __builtin_amdgcn_alignbit(W[p][d0 + 4], W[p][d0 + 3], 16));
+                    else
+                        f = make_uint4(W[p][d0], W[p][d0 + 1], W[p][d0 + 2], W[p][d0 + 3]);
+                    Bt[p] = __builtin_bit_cast(bf16x8, f);
+                }
+                acc[tap] = mfma_bf16x6(A, Bt, acc[tap]);
+                if (tap == 0) load_piece(nextc, kb);                 // pieces 0..7 ride along the matrix phase
+            }
+        }
+        load_piece(nextc, NV);
+        __syncthreads();
+        if (next < ntiles) write_tile(next);
+        __syncthreads();
+        tile = next;
+    }
+
+    float* out = a.partial + (size_t)blockIdx.x * (KW * 4096 + 64);
+    // every wave owns its block of the slab: straight to global (128-B row segments)
+#pragma unroll
+    for (int k = 0; k < KW; ++k)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) out[(k * 64 + mt * 32 + mfma_row(r, half)) * 64 + nt * 32 + l31] = acc[k][r];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const float v = half_wave_sum(bsum[i]);
+        if (l31 == 0) out[KW * 4096 + c0 + 8 * i] = v;
+    }
+}
+
+template <int XPRO>
+int launch_wgrad64bf7(const Wgrad64Args& a, int* grid_out, hipStream_t stream) {
+    constexpr size_t lds = (size_t)(3 * 64 * 136 + 3 * 64 * 152) * 2;
+    static bool attr_done = false;
+    auto kern = wgrad64bf7_kernel<XPRO>;
+    if (!attr_done) {
+        WM_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    const int ntiles = a.B * ((a.T + 127) / 128);
+    const int grid = ntiles < kNumCU ? ntiles : kNumCU;
+    *grid_out = grid;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, a);
+    WM_CHECK_LAUNCH();
+    return 0;
+}
+
 }  // namespace
 
 // =============================================================================================
@@ -1856,6 +2034,22 @@ int wm_conv64_bf7(const float* x, const void* wpb, const float* vec, const float
     if (pro == PRO_ADDVEC && epi == EPI_BIAS) return launch_conv64bf7<PRO_ADDVEC, EPI_BIAS>(a, stream);
     if (pro == PRO_NONE && epi == EPI_NONE) return launch_conv64bf7<PRO_NONE, EPI_NONE>(a, stream);
     return (int)hipErrorInvalidValue;
+}
+
+// bf16x6 build of the 7-tap ConvTranspose1d weight gradient (= wm_wgrad64 with KW 7, gpro 0, layout 1): dw [in][out][7]
+int wm_wgrad64_bf7(const float* g, const float* x, const float* vec, float* partial, float* dw, float* dbias, int B, int T,
+                   int xpro, int accumulate, hipStream_t stream) {
+    if (B <= 0 || T <= 0 || (T & 3)) return (int)hipErrorInvalidValue;
+    Wgrad64Args a{g, nullptr, nullptr, nullptr, nullptr, x, vec, nullptr, partial, B, T};
+    int grid = 0, rc = (int)hipErrorInvalidValue;
+    if (xpro == PRO_ADDVEC) rc = launch_wgrad64bf7<PRO_ADDVEC>(a, &grid, stream);
+    else if (xpro == PRO_NONE) rc = launch_wgrad64bf7<PRO_NONE>(a, &grid, stream);
+    if (rc) return rc;
+    const int n = 7 * 4096 + 64;
+    hipLaunchKernelGGL(wgrad64_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, (const float*)partial, grid, 7, 1, dw,
+                       dbias, accumulate);
+    WM_CHECK_LAUNCH();
+    return 0;
 }
 
 // bf16x6 build of the k3 weight gradient (same contract as wm_wgrad64 with KW = 3, layout 0)

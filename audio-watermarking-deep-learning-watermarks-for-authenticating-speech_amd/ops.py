@@ -445,6 +445,10 @@ class ConvT7Fn(torch.autograd.Function):
 
         def wg():
             part = _f32(2 * NCU * (7 * 4096 + 64), device=dev)
+            if _CONV["bf16x6"]:
+                lib.wm_wgrad64_bf7(_p(g), _p(x), _p(vec), _p(part), _p(gw if side else dw), _p(gbias if side else db), B, T,
+                                   2 if vec is not None else 0, 1 if side else 0, _stream())
+                return
             lib.wm_wgrad64(_p(g), None, None, None, None, _p(x), _p(vec), None, _p(part), _p(gw if side else dw),
                            _p(gbias if side else db), B, T, 7, 0, 2 if vec is not None else 0, 1, 1 if side else 0, _stream())
         dw, db = (None, None) if side else (torch.empty_like(w), _f32(64, device=dev))

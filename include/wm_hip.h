@@ -64,6 +64,11 @@ int wm_pack_w64_bf7(const float* w, void* wpb, int mode, wm_stream_t stream);
 int wm_conv64_bf7(const float* x, const void* wpb, const float* vec, const float* bias, float* y, int B, int T, int pro, int epi,
                   wm_stream_t stream);
 
+/* weight gradient of that ConvTranspose1d (= wm_wgrad64 with KW 7, gpro 0, layout 1): dw [in][out][7], dbias [64];
+ * xpro 0 | 2 (x + vec[b*64+c]); partial: >= 256 * (7*4096 + 64) floats. */
+int wm_wgrad64_bf7(const float* g, const float* x, const float* vec, float* partial, float* dw, float* dbias, int B, int T,
+                   int xpro, int accumulate, wm_stream_t stream);
+
 /* bf16x6 build of the k3 Conv1d weight gradient (contract of wm_wgrad64 with KW = 3, layout 0) */
 int wm_wgrad64_bf(const float* g, const float* g2, const float* ga, const float* gb, const float* gc,
                   const float* x, const float* xa, const float* xb, float* partial, float* dw, float* dbias,

@@ -66,6 +66,7 @@ timeit("wgrad64 k3 bnbwd x none", lambda: lib.wm_wgrad64(_p(x), _p(x2), _p(c[0])
 timeit("wgrad64bf k3 bnbwd x bnrelu", lambda: lib.wm_wgrad64_bf(_p(x), _p(x2), _p(c[0]), _p(c[1]), _p(c[2]), _p(x3), _p(c[3]), _p(c[4]), _p(wpart), _p(dw3), _p(db), B, T, 3, 1, 0, st), F3, 3 * FR)
 timeit("wgrad64bf k3 bnbwd x none", lambda: lib.wm_wgrad64_bf(_p(x), _p(x2), _p(c[0]), _p(c[1]), _p(c[2]), _p(x3), None, None, _p(wpart), _p(dw3), _p(db), B, T, 3, 0, 0, st), F3, 3 * FR)
 timeit("wgrad64 k7 none x addvec", lambda: lib.wm_wgrad64(_p(x), None, None, None, None, _p(x3), _p(vec), None, _p(wpart), _p(dw7), _p(db), B, T, 7, 0, 2, 1, 0, st), F7, 2 * FR)
+timeit("wgrad64bf7 k7 none x addvec", lambda: lib.wm_wgrad64_bf7(_p(x), _p(x2), _p(vec), _p(wpart), _p(dw7), _p(db), B, T, 2, 0, st), F7, 2 * FR)
 timeit("bn_add_relu", lambda: lib.wm_bn_add_relu(_p(x), _p(x2), _p(c[0]), _p(c[1]), _p(y), B, T, st), None, 3 * FR)
 part = _f32(B * 128, device=dev)
 timeit("relu_bwd_reduce", lambda: lib.wm_relu_bwd_reduce(_p(x), _p(x2), _p(x3), _p(y), _p(part), B, T, st), None, 4 * FR)
