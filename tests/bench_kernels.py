@@ -97,3 +97,10 @@ w17 = torch.randn(17, 64, 1, device=dev); b17 = torch.randn(17, device=dev); lg 
 timeit("headN_fwd (2B)", lambda: lib.wm_headN_fwd(_p(X2), _p(w17), _p(b17), _p(lg), 2 * B, T, 17, st), None, 2 * FR * 1.27)
 hp = _f32(256 * (17 * 64 + 17), device=dev); dw17 = torch.empty_like(w17); db17 = _f32(17, device=dev)
 timeit("headN_bwd (2B)", lambda: lib.wm_headN_bwd(_p(lg), _p(X2), _p(w17), _p(Y2), _p(hp), _p(dw17), _p(db17), 2 * B, T, 17, 0, st), None, 2 * FR * 2.27)
+# ---- BCE over the (2B, T, 17) logits
+lg = torch.randn(2 * B, T, 17, device=dev) * 3
+msgs = torch.randint(0, 65536, (B,), device=dev)
+bpart = _f32(2 * 2 * B * ((T * 17 + 4095) // 4096), device=dev); bout = torch.zeros(2, device=dev); dlg = torch.empty_like(lg)
+gl = torch.ones(1, device=dev)
+timeit("bce_fwd", lambda: lib.wm_bce_fwd(_p(lg), _p(msgs), _p(bpart), _p(bout[0]), _p(bout[1]), B, 2 * B, T, 17, st), None, 2 * B * T * 17 * 4.0)
+timeit("bce_bwd", lambda: lib.wm_bce_bwd(_p(lg), _p(msgs), _p(gl), _p(gl), _p(dlg), B, 2 * B, T, 17, st), None, 2 * 2 * B * T * 17 * 4.0)
