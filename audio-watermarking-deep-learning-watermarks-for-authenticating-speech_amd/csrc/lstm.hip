@@ -688,14 +688,14 @@ __global__ __launch_bounds__(256) void lstm_dx_kernel(const float* __restrict__ 
     for (int i = tid; i < 256 * 16; i += 256)      // row n' of the LDS image = parameter row gate_row(n')
         reinterpret_cast<float4*>(ws)[i] = reinterpret_cast<const float4*>(w_ih)[gate_row(i >> 4) * 16 + (i & 15)];
     float4 st[16];
-    auto load_tile = [&](int tile) {               // branch-free: rows past T read a clamped row, never stored
+    auto load_piece = [&](int tile, int k) {       // branch-free: rows past T read a clamped row, never stored
         const int b = tile / tilesPerClip, t0 = (tile % tilesPerClip) * NT;
-        const float4* dab = reinterpret_cast<const float4*>(da + (size_t)b * T * 256);
+        const int i = tid + k * 256;
+        st[k] = reinterpret_cast<const float4*>(da + (size_t)b * T * 256)[(size_t)min(t0 + (i >> 6), T - 1) * 64 + (i & 63)];
+    };
+    auto load_tile = [&](int tile) {
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const int i = tid + k * 256;
-            st[k] = dab[(size_t)min(t0 + (i >> 6), T - 1) * 64 + (i & 63)];
-        }
+        for (int k = 0; k < 16; ++k) load_piece(tile, k);
     };
     auto write_tile = [&]() {
 #pragma unroll
@@ -714,13 +714,16 @@ __global__ __launch_bounds__(256) void lstm_dx_kernel(const float* __restrict__ 
     const float* ap = ws + half * 64 + mt * 32 + l31;
     const float* bp = ds + (nt * 32 + l31) * DS + half;
     while (tile < ntiles) {
-        const int next = tile + gridDim.x;
-        if (next < ntiles) load_tile(next);
+        const int next = tile + gridDim.x, nextc = min(next, ntiles - 1);     // clamped: loaded (valid memory), never written
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll 8
-        for (int s = 0; s < 128; ++s) acc = mfma32(ap[2 * s * 64], bp[2 * s], acc);
+#pragma unroll
+        for (int g8 = 0; g8 < 16; ++g8) {              // the next tile's 64 KB arrive one piece per 8 MFMAs, not as one burst
+            load_piece(nextc, g8);
+#pragma unroll
+            for (int s = 8 * g8; s < 8 * g8 + 8; ++s) acc = mfma32(ap[2 * s * 64], bp[2 * s], acc);
+        }
         const int b = tile / tilesPerClip, t0 = (tile % tilesPerClip) * NT;
         const int t = t0 + nt * 32 + l31;
         if (t < T) {
@@ -757,22 +760,26 @@ __global__ __launch_bounds__(256) void lstm_wgrad_kernel(const float* __restrict
     float bsum = 0.f;
     float4 sd[16], sx[4], sh[4];
     float hh;
-    auto load_tile = [&](int tile) {               // branch-free (clamped addresses), masked when written to LDS
+    // piece p of a tile's staging: 0..15 da rows, 16..19 x, 20..23 h, 24 the halo column h[t0 - 1].  Branch-free (clamped
+    // addresses), masked when written to LDS.  The main loop issues one piece per k-step: the 96-KB tile would otherwise
+    // hit the memory pipeline as one burst and block the wave at issue (see conv64bf3_kernel).
+    auto load_piece = [&](int tile, int p) {
         const int b = tile / tilesPerClip, t0 = (tile % tilesPerClip) * NT;
-        const float4* dab = reinterpret_cast<const float4*>(da + (size_t)b * T * 256);
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const int i = tid + k * 256;
-            sd[k] = dab[(size_t)min(t0 + (i >> 6), T - 1) * 64 + (i & 63)];
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int i = tid + k * 256, j = i >> 4, q = i & 15;
+        if (p < 16) {
+            const int i = tid + p * 256;
+            sd[p] = reinterpret_cast<const float4*>(da + (size_t)b * T * 256)[(size_t)min(t0 + (i >> 6), T - 1) * 64 + (i & 63)];
+        } else if (p < 24) {
+            const int k = p & 3, i = tid + k * 256, j = i >> 4, q = i & 15;
             const size_t off = ((size_t)b * 64 + j) * T + min(t0 + 4 * q, T - 4);
-            sx[k] = *reinterpret_cast<const float4*>(x + off);
-            sh[k] = *reinterpret_cast<const float4*>(h + off);
+            if (p < 20) sx[k] = *reinterpret_cast<const float4*>(x + off);
+            else sh[k] = *reinterpret_cast<const float4*>(h + off);
+        } else {
+            hh = h[((size_t)b * 64 + (tid & 63)) * T + max(t0 - 1, 0)];
         }
-        hh = h[((size_t)b * 64 + (tid & 63)) * T + max(t0 - 1, 0)];      // halo column h[t0 - 1]
+    };
+    auto load_tile = [&](int tile) {
+#pragma unroll
+        for (int p = 0; p < 25; ++p) load_piece(tile, p);
     };
     auto write_tile = [&](int tile) {
         const int t0 = (tile % tilesPerClip) * NT;
@@ -802,10 +809,10 @@ __global__ __launch_bounds__(256) void lstm_wgrad_kernel(const float* __restrict
     const float* ap = ds + half * 256 + wave * 64 + l31;
     const float* bp = zs + l31 * ZS + half;
     while (tile < ntiles) {
-        const int next = tile + gridDim.x;
-        if (next < ntiles) load_tile(next);
-#pragma unroll 4
+        const int next = tile + gridDim.x, nextc = min(next, ntiles - 1);     // clamped: loaded (valid memory), never written
+#pragma unroll
         for (int s = 0; s < NT / 2; ++s) {
+            if (s < 25) load_piece(nextc, s);
             const float a0 = ap[2 * s * 256], a1 = ap[2 * s * 256 + 32];
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {

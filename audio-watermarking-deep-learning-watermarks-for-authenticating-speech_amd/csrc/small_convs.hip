@@ -262,27 +262,28 @@ __global__ __launch_bounds__(256) void head1_bwd_kernel(const float* __restrict_
 template <int NO>
 __global__ __launch_bounds__(256) void headN_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ bias, float* __restrict__ y, int T) {
-    __shared__ float ws[NO * 64 + NO];
+    // One thread = one time step: its 64 channel values sit in registers and every weight is a wave-uniform scalar
+    // operand (s_load through the scalar cache) -- the first version broadcast the weights through LDS reads, whose
+    // return path (64 lanes x 16 B per read) bounded the kernel at half the HBM rate.
     __shared__ float os[256 * NO];
     const int tilesPerClip = (T + 255) / 256;
     const int b = blockIdx.x / tilesPerClip, t0 = (blockIdx.x % tilesPerClip) * 256;
-    for (int i = threadIdx.x; i < NO * 64 + NO; i += 256) ws[i] = (i < NO * 64) ? w[i] : bias[i - NO * 64];
-    __syncthreads();
-    const int t = t0 + threadIdx.x;
-    float acc[NO];
+    const int t = min(t0 + (int)threadIdx.x, T - 1);           // clamped: lanes past T compute a copy that is never stored
+    const float* xb = x + (size_t)b * 64 * T + t;
+    float v[64];
 #pragma unroll
-    for (int o = 0; o < NO; ++o) acc[o] = ws[NO * 64 + o];
-    if (t < T) {
-        const float* xb = x + (size_t)b * 64 * T + t;
-#pragma unroll 4
-        for (int c = 0; c < 64; ++c) {
-            const float v = xb[(size_t)c * T];
+    for (int c = 0; c < 64; ++c) v[c] = xb[(size_t)c * T];
 #pragma unroll
-            for (int o = 0; o < NO; ++o) acc[o] = fmaf(ws[o * 64 + c], v, acc[o]);
+    for (int o = 0; o < NO; ++o) {
+        const float* wo = w + o * 64;                            // uniform address: scalar loads
+        float a0 = bias[o], a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+        for (int c = 0; c < 64; c += 4) {
+            a0 = fmaf(wo[c], v[c], a0); a1 = fmaf(wo[c + 1], v[c + 1], a1);
+            a2 = fmaf(wo[c + 2], v[c + 2], a2); a3 = fmaf(wo[c + 3], v[c + 3], a3);
         }
+        os[threadIdx.x * NO + o] = (a0 + a1) + (a2 + a3);
     }
-#pragma unroll
-    for (int o = 0; o < NO; ++o) os[threadIdx.x * NO + o] = acc[o];
     __syncthreads();
     const int nvalid = min(256, T - t0) * NO;
     float* yb = y + ((size_t)b * T + t0) * NO;
@@ -314,19 +315,23 @@ __global__ __launch_bounds__(256) void headN_bwd_kernel(const float* __restrict_
     // next tile is fetched into registers (16-B loads, clamped addresses, no branches) while this one is processed
     constexpr int NG4 = (256 * NO + 3) / 4, NGV = (NG4 + 255) / 256;
     float4 sx[16], sgv[NGV];
-    auto load_tile = [&](int tile) {
+    // piece p of the staging: 0..15 x rows, 16.. the g tile.  The main loop issues one piece per k-step of the dw product
+    // (an 81-KB burst would block the wave at issue, see conv64bf3_kernel)
+    auto load_piece = [&](int tile, int p) {
         const int b = tile / tilesPerClip, t0 = (tile % tilesPerClip) * 256;
-        const float* xb = x + (size_t)b * 64 * T;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const int i = tid + k * 256, c = i >> 6, q = i & 63;
-            sx[k] = *reinterpret_cast<const float4*>(xb + (size_t)c * T + min(t0 + 4 * q, T - 4));
+        if (p < 16) {
+            const int i = tid + p * 256, c = i >> 6, q = i & 63;
+            sx[p] = *reinterpret_cast<const float4*>(x + ((size_t)b * 64 + c) * T + min(t0 + 4 * q, T - 4));
+        } else {
+            // the g tile is 256*NO contiguous floats starting at a 16-B aligned address (t0 % 256 == 0, T % 4 == 0)
+            const float4* gb4 = reinterpret_cast<const float4*>(g + ((size_t)b * T + t0) * NO);
+            const int lim4 = ((T - t0 < 256 ? T - t0 : 256) * NO) / 4;        // whole float4s available in this clip
+            sgv[p - 16] = gb4[min(tid + (p - 16) * 256, lim4 - 1)];
         }
-        // the g tile is 256*NO contiguous floats starting at a 16-B aligned address (t0 % 256 == 0, T % 4 == 0)
-        const float4* gb4 = reinterpret_cast<const float4*>(g + ((size_t)b * T + t0) * NO);
-        const int lim4 = ((T - t0 < 256 ? T - t0 : 256) * NO) / 4;            // whole float4s available in this clip
+    };
+    auto load_tile = [&](int tile) {
 #pragma unroll
-        for (int k = 0; k < NGV; ++k) sgv[k] = gb4[min(tid + k * 256, lim4 - 1)];
+        for (int p = 0; p < 16 + NGV; ++p) load_piece(tile, p);
     };
     auto write_tile = [&](int tile) {
         const int t0 = (tile % tilesPerClip) * 256;
@@ -358,8 +363,7 @@ __global__ __launch_bounds__(256) void headN_bwd_kernel(const float* __restrict_
     if (tile < ntiles) write_tile(tile);
     __syncthreads();
     while (tile < ntiles) {
-        const int next = tile + gridDim.x;
-        if (next < ntiles) load_tile(next);
+        const int next = tile + gridDim.x, nextc = min(next, ntiles - 1);     // clamped: loaded (valid memory), never written
         const int b = tile / tilesPerClip, t0 = (tile % tilesPerClip) * 256;
         const int nt = min(256, T - t0);
         // ---- dx tile: D[c][t]
@@ -393,15 +397,19 @@ __global__ __launch_bounds__(256) void headN_bwd_kernel(const float* __restrict_
         {
             const float* ap = gsm + (wave * 64 + half) * GS + l31;
             const float* bp = xs + l31 * XS + wave * 64 + half;
-#pragma unroll 8
+#pragma unroll
             for (int s = 0; s < 32; ++s) {
+                if (s < 16 + NGV) load_piece(nextc, s);
                 const float a = ap[2 * s * GS];
                 accw[0] = mfma32(a, bp[2 * s], accw[0]);
                 accw[1] = mfma32(a, bp[32 * XS + 2 * s], accw[1]);
             }
         }
-        if (tid < NO)
-            for (int tt = 0; tt < 256; ++tt) accb += gsm[tt * GS + tid];
+        if (tid < 8 * 32 && (tid & 31) < NO) {          // bias sums: output tid & 31, 32-step segment tid >> 5 (8 short loops, not one long one)
+            const float* gp = gsm + (tid >> 5) * 32 * GS + (tid & 31);
+#pragma unroll 8
+            for (int tt = 0; tt < 32; ++tt) accb += gp[tt * GS];
+        }
         __syncthreads();
         if (next < ntiles) write_tile(next);
         __syncthreads();
@@ -424,7 +432,12 @@ __global__ __launch_bounds__(256) void headN_bwd_kernel(const float* __restrict_
     }
     float* out = partial + (size_t)blockIdx.x * (NO * 64 + NO);
     for (int i = tid; i < NO * 64; i += 256) out[i] = red[i];
-    if (tid < NO) out[NO * 64 + tid] = accb;
+    __syncthreads();
+    red[tid] = ((tid & 31) < NO) ? accb : 0.f;          // [8 segments][32]
+    __syncthreads();
+    if (tid < NO)
+        out[NO * 64 + tid] = ((red[tid] + red[32 + tid]) + (red[64 + tid] + red[96 + tid])) +
+                             ((red[128 + tid] + red[160 + tid]) + (red[192 + tid] + red[224 + tid]));
 }
 
 }  // namespace
