@@ -537,14 +537,26 @@ int launch_wgrad64(const Wgrad64Args& a, int* grid_out, hipStream_t stream) {
 
 // dst layout: mode 0 conv  dW[out][in][KW]   <- G[tap][out][in]
 //             mode 1 convT dW[in][out][KW]   <- G[KW-1-k][out][in]
-__global__ void wgrad64_reduce_kernel(const float* __restrict__ partial, int nparts, int KW, int mode,
-                                      float* __restrict__ dw, float* __restrict__ dbias, int accumulate) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void wgrad64_reduce_kernel(const float* __restrict__ partial, int nparts, int KW, int mode,
+                                                             float* __restrict__ dw, float* __restrict__ dbias, int accumulate) {
+    // block = 64 outputs x 4 quarters of the slab list; fixed order, fp64: bitwise reproducible and cancellation-safe
+    __shared__ double sq[4][64];
+    const int il = threadIdx.x & 63, grp = threadIdx.x >> 6, i = blockIdx.x * 64 + il;
     const int stride = KW * 4096 + 64;
-    if (i >= stride) return;
-    double sd = 0.0;                                    // fixed order, fp64: bitwise reproducible and cancellation-safe
-    for (int p = 0; p < nparts; ++p) sd += (double)partial[(size_t)p * stride + i];
-    const float s = (float)sd;
+    const int per = (nparts + 3) / 4, p0 = grp * per, p1 = min(p0 + per, nparts);
+    double s0 = 0.0, s1 = 0.0;
+    if (i < stride) {
+        int p = p0;
+        for (; p + 1 < p1; p += 2) {
+            s0 += (double)partial[(size_t)p * stride + i];
+            s1 += (double)partial[(size_t)(p + 1) * stride + i];
+        }
+        if (p < p1) s0 += (double)partial[(size_t)p * stride + i];
+    }
+    sq[grp][il] = s0 + s1;
+    __syncthreads();
+    if (grp != 0 || i >= stride) return;
+    const float s = (float)((sq[0][il] + sq[1][il]) + (sq[2][il] + sq[3][il]));
     if (i < KW * 4096) {
         const int tap = i / 4096, out = (i / 64) % 64, in = i % 64;
         const int dst = (mode == 0) ? (out * 64 + in) * KW + tap : (in * 64 + out) * KW + (KW - 1 - tap);
@@ -2046,7 +2058,7 @@ int wm_wgrad64_bf7(const float* g, const float* x, const float* vec, float* part
     else if (xpro == PRO_NONE) rc = launch_wgrad64bf7<PRO_NONE>(a, &grid, stream);
     if (rc) return rc;
     const int n = 7 * 4096 + 64;
-    hipLaunchKernelGGL(wgrad64_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, (const float*)partial, grid, 7, 1, dw,
+    hipLaunchKernelGGL(wgrad64_reduce_kernel, dim3((n + 63) / 64), dim3(256), 0, stream, (const float*)partial, grid, 7, 1, dw,
                        dbias, accumulate);
     WM_CHECK_LAUNCH();
     return 0;
@@ -2063,7 +2075,7 @@ int wm_wgrad64_bf(const float* g, const float* g2, const float* ga, const float*
     else if (gpro == PRO_BNBWD && xpro == PRO_NONE) rc = launch_wgrad64bf<PRO_BNBWD, PRO_NONE>(a, &grid, stream);
     if (rc) return rc;
     const int n = 3 * 4096 + 64;
-    hipLaunchKernelGGL(wgrad64_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, (const float*)partial, grid, 3, 0, dw,
+    hipLaunchKernelGGL(wgrad64_reduce_kernel, dim3((n + 63) / 64), dim3(256), 0, stream, (const float*)partial, grid, 3, 0, dw,
                        dbias, accumulate);
     WM_CHECK_LAUNCH();
     return 0;
@@ -2084,7 +2096,7 @@ int wm_wgrad64(const float* g, const float* g2, const float* ga, const float* gb
     else if (KW == 7 && gpro == PRO_NONE && xpro == PRO_NONE) rc = launch_wgrad64<7, PRO_NONE, PRO_NONE>(a, &grid, stream);
     if (rc) return rc;
     const int n = KW * 4096 + 64;
-    hipLaunchKernelGGL(wgrad64_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, (const float*)partial, grid, KW,
+    hipLaunchKernelGGL(wgrad64_reduce_kernel, dim3((n + 63) / 64), dim3(256), 0, stream, (const float*)partial, grid, KW,
                        layout, dw, dbias, accumulate);
     WM_CHECK_LAUNCH();
     return 0;

@@ -74,13 +74,15 @@ __global__ __launch_bounds__(256) void stem_bwd_kernel(const float* __restrict__
     for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
     float4 sg[16];
     float hg[2], sv[2];
-    auto load_tile = [&](int tile) {                 // branch-free (clamped addresses)
+    // piece p < 16: one row group of the g tile; piece 16: halo columns + the clip samples.  Branch-free (clamped addresses).
+    // The main loop issues one piece per two k-steps of the dw product instead of the whole 64-KB tile at once.
+    auto load_piece = [&](int tile, int p) {
         const int b = tile / tilesPerClip, t0 = (tile % tilesPerClip) * NT;
         const float* gb = g + (size_t)b * 64 * T;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const int i = tid + k * 256, c = i >> 6, q = i & 63;
-            sg[k] = *reinterpret_cast<const float4*>(gb + (size_t)c * T + min(t0 + 4 * q, T - 4));
+        if (p < 16) {
+            const int i = tid + p * 256, c = i >> 6, q = i & 63;
+            sg[p] = *reinterpret_cast<const float4*>(gb + (size_t)c * T + min(t0 + 4 * q, T - 4));
+            return;
         }
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
@@ -90,6 +92,10 @@ __global__ __launch_bounds__(256) void stem_bwd_kernel(const float* __restrict__
             const int ts_ = t0 - 3 + tid + k * 256;
             sv[k] = s[(size_t)b * T + min(max(ts_, 0), T - 1)];
         }
+    };
+    auto load_tile = [&](int tile) {
+#pragma unroll
+        for (int p = 0; p <= 16; ++p) load_piece(tile, p);
     };
     auto write_tile = [&](int tile) {
         const int t0 = (tile % tilesPerClip) * NT;
@@ -120,16 +126,16 @@ __global__ __launch_bounds__(256) void stem_bwd_kernel(const float* __restrict__
     if (tile < ntiles) write_tile(tile);
     __syncthreads();
     while (tile < ntiles) {
-        const int next = tile + gridDim.x;
-        if (next < ntiles) load_tile(next);
+        const int next = tile + gridDim.x, nextc = min(next, ntiles - 1);     // clamped: loaded (valid memory), never written
         const int b = tile / tilesPerClip, t0 = (tile % tilesPerClip) * NT;
         // ---- dw / db: this wave's 64 time steps.  A[i = co][k = t] = gs[co][t];  B[k = t][j] = s[t + j - 3] (j < 7), 1 (j == 7), 0
         {
             const float* ap = gs + l31 * GS + 4 + wave * 64 + half;
             const float* bp = ss + wave * 64 + half + l31;        // ss[t - t0 + j] = s[t + j - 3]
             const bool tapcol = l31 < 7, onecol = l31 == 7;
-#pragma unroll 8
+#pragma unroll
             for (int k2 = 0; k2 < 32; ++k2) {
+                if ((k2 & 1) == 0 || k2 == 31) load_piece(nextc, k2 == 31 ? 16 : k2 >> 1);
                 const float sval = bp[2 * k2];
                 const float bv = tapcol ? sval : (onecol ? 1.f : 0.f);
                 acc[0] = mfma32(ap[2 * k2], bv, acc[0]);
@@ -185,14 +191,28 @@ __global__ __launch_bounds__(256) void stem_bwd_kernel(const float* __restrict__
     for (int i = tid; i < 512; i += 256) out[i] = red[i];
 }
 
-// out[i] (+)= sum_p partial[p*stride + i],  i < count
-__global__ void reduce_partials_kernel(const float* __restrict__ partial, int nparts, int stride, int count,
-                                       float* __restrict__ out, int accumulate) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= count) return;
-    double s = 0.0;
-    for (int p = 0; p < nparts; ++p) s += (double)partial[(size_t)p * stride + i];
-    out[i] = accumulate ? out[i] + (float)s : (float)s;
+// out[i] (+)= sum_p partial[p*stride + i],  i < count.  Block = 64 outputs x 4 quarters of the slab list (fp64, fixed
+// order: bit-reproducible); launch with 256 threads and ceil(count / 64) blocks.
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial, int nparts, int stride, int count,
+                                                              float* __restrict__ out, int accumulate) {
+    __shared__ double sq[4][64];
+    const int il = threadIdx.x & 63, grp = threadIdx.x >> 6, i = blockIdx.x * 64 + il;
+    const int per = (nparts + 3) / 4, p0 = grp * per, p1 = min(p0 + per, nparts);
+    double s0 = 0.0, s1 = 0.0;
+    if (i < count) {
+        int p = p0;
+        for (; p + 1 < p1; p += 2) {
+            s0 += (double)partial[(size_t)p * stride + i];
+            s1 += (double)partial[(size_t)(p + 1) * stride + i];
+        }
+        if (p < p1) s0 += (double)partial[(size_t)p * stride + i];
+    }
+    sq[grp][il] = s0 + s1;
+    __syncthreads();
+    if (grp == 0 && i < count) {
+        const float s = (float)((sq[0][il] + sq[1][il]) + (sq[2][il] + sq[3][il]));
+        out[i] = accumulate ? out[i] + s : s;
+    }
 }
 // stem partial [nparts][64][8] -> dw[64][7], db[64]
 __global__ void stem_reduce_kernel(const float* __restrict__ partial, int nparts, float* dw, float* db, int accumulate) {
@@ -489,9 +509,9 @@ int wm_head1_bwd(const float* g, const float* x, const float* w, float* dx, floa
     hipLaunchKernelGGL(head1_bwd_kernel, dim3(grid), dim3(256), 0, stream, g, x, w, dx, partial, T / 4, total4);
     WM_CHECK_LAUNCH();
     // partial [grid][65]: first 64 -> dw, last -> db
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(64), 0, stream, (const float*)partial, grid, 65, 64, dw, accumulate);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, stream, (const float*)partial, grid, 65, 64, dw, accumulate);
     WM_CHECK_LAUNCH();
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(64), 0, stream, (const float*)partial + 64, grid, 65, 1, db, accumulate);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, stream, (const float*)partial + 64, grid, 65, 1, db, accumulate);
     WM_CHECK_LAUNCH();
     return 0;
 }
@@ -523,9 +543,9 @@ int wm_headN_bwd(const float* g, const float* x, const float* w, float* dx, floa
     WM_CHECK_LAUNCH();
     const int n = NO * 64 + NO;
     // partial rows are [NO*64 weights | NO biases]; reduce the two pieces with matching row stride
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((NO * 64 + 255) / 256), dim3(256), 0, stream, (const float*)partial, grid, n, NO * 64, dw, accumulate);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((NO * 64 + 63) / 64), dim3(256), 0, stream, (const float*)partial, grid, n, NO * 64, dw, accumulate);
     WM_CHECK_LAUNCH();
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(64), 0, stream, (const float*)partial + NO * 64, grid, n, NO, db, accumulate);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, stream, (const float*)partial + NO * 64, grid, n, NO, db, accumulate);
     WM_CHECK_LAUNCH();
     return 0;
 }
