@@ -737,6 +737,85 @@ __global__ __launch_bounds__(256) void lstm_dx_kernel(const float* __restrict__ 
     }
 }
 
+// ------------------------------------------------------------------------------------ dx GEMM, bf16x6
+// Same product as lstm_dx_kernel on the bf16 matrix cores (bf16x6 split, fp32-grade).  The contraction runs over the gate
+// column n', which is the contiguous axis of da [t][n']: a B fragment (one time step, 8 consecutive n') is one aligned
+// ds_read_b128 of the 3-piece LDS image of the tile, no transposition.  W_ih^T lives in registers as A fragments
+// (16 k-steps x 3 pieces = 192 VGPRs for this wave's 32 channels).  Wave = (channel half mt, time half nt) of a 64-step tile.
+__global__ __launch_bounds__(256) void lstm_dx_bf_kernel(const float* __restrict__ da, const float* __restrict__ w_ih,
+                                                         float* __restrict__ dx, int B, int T) {
+    constexpr int NT = 64, NP = 3, PD = 264;         // image row pitch in bf16 (528 B = 33 x 16 B)
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    unsigned short* Db = reinterpret_cast<unsigned short*>(smem_raw);          // [NP][NT][PD]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const int mt = wave & 1, nt = wave >> 1;
+    const int tilesPerClip = (T + NT - 1) / NT, ntiles = B * tilesPerClip;
+    // A[i = channel mt*32 + l31][k = n' = 16 ks + 8 half + j] = w_ih[gate_row(n')][channel]
+    bf16x8 Wt[16][NP];
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = w_ih[gate_row(16 * ks + 8 * half + j) * 64 + mt * 32 + l31];
+        unsigned a[4], m[4], l[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) split3_pair(v[2 * j], v[2 * j + 1], a[j], m[j], l[j]);
+        Wt[ks][0] = __builtin_bit_cast(bf16x8, make_uint4(a[0], a[1], a[2], a[3]));
+        Wt[ks][1] = __builtin_bit_cast(bf16x8, make_uint4(m[0], m[1], m[2], m[3]));
+        Wt[ks][2] = __builtin_bit_cast(bf16x8, make_uint4(l[0], l[1], l[2], l[3]));
+    }
+    float4 st[16];
+    auto load_piece = [&](int tile, int k) {       // branch-free: rows past T read a clamped row, never stored
+        const int b = tile / tilesPerClip, t0 = (tile % tilesPerClip) * NT;
+        const int i = tid + k * 256;
+        st[k] = reinterpret_cast<const float4*>(da + (size_t)b * T * 256)[(size_t)min(t0 + (i >> 6), T - 1) * 64 + (i & 63)];
+    };
+    auto write_tile = [&]() {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int i = tid + k * 256;
+            unsigned a0, a1, a2, b0, b1, b2;
+            split3_pair(st[k].x, st[k].y, a0, a1, a2);
+            split3_pair(st[k].z, st[k].w, b0, b1, b2);
+            unsigned short* d = Db + (i >> 6) * PD + 4 * (i & 63);
+            *reinterpret_cast<uint2*>(d) = make_uint2(a0, b0);
+            *reinterpret_cast<uint2*>(d + NT * PD) = make_uint2(a1, b1);
+            *reinterpret_cast<uint2*>(d + 2 * NT * PD) = make_uint2(a2, b2);
+        }
+    };
+    int tile = blockIdx.x;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) load_piece(min(tile, ntiles - 1), k);
+    __syncthreads();
+    write_tile();
+    __syncthreads();
+    const unsigned short* brow = Db + (nt * 32 + l31) * PD + 8 * half;
+    while (tile < ntiles) {
+        const int next = tile + gridDim.x, nextc = min(next, ntiles - 1);     // clamped: loaded (valid memory), never written
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            bf16x8 Bf[NP];
+#pragma unroll
+            for (int p = 0; p < NP; ++p) Bf[p] = *reinterpret_cast<const bf16x8*>(brow + p * NT * PD + 16 * ks);
+            acc = mfma_bf16x6(Wt[ks], Bf, acc);
+            load_piece(nextc, ks);                 // the next tile's 64 KB arrive one piece per k-step
+        }
+        const int b = tile / tilesPerClip, t0 = (tile % tilesPerClip) * NT;
+        const int t = t0 + nt * 32 + l31;
+        if (t < T) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dx[((size_t)b * 64 + mt * 32 + mfma_row(r, half)) * T + t] = acc[r];
+        }
+        __syncthreads();
+        if (next < ntiles) write_tile();
+        __syncthreads();
+        tile = next;
+    }
+}
+
 // ---------------------------------------------------------------------------------- wgrad GEMM
 // G[n'][j] = sum_{b,t} da[b,t,n'] * z[b,j,t],  z = [x (64 rows) ; h shifted by one step (64 rows)]
 // persistent blocks over (clip, 64-step) tiles, next tile prefetched into registers during the MFMA phase;
@@ -919,11 +998,22 @@ int wm_lstm_bwd_fused(float* gates, const float* cst, const float* dh_out, const
     return 0;
 }
 
+static int g_lstm_dx_bf = 1;        // 1: bf16x6 split on the bf16 matrix cores (default) | 0: native fp32 MFMA
+int wm_set_lstm_dx_bf16x6(int on, hipStream_t) { g_lstm_dx_bf = on ? 1 : 0; return 0; }
+
 int wm_lstm_dx(const float* da, const float* w_ih, float* dx, int B, int T, hipStream_t stream) {
+    const int ntiles = B * ((T + 63) / 64);
+    if (g_lstm_dx_bf) {
+        constexpr size_t ldsb = (size_t)3 * 64 * 264 * 2;
+        static bool doneb = false;
+        if (!doneb) { WM_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_dx_bf_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb)); doneb = true; }
+        hipLaunchKernelGGL(lstm_dx_bf_kernel, dim3(ntiles < kNumCU ? ntiles : kNumCU), dim3(256), ldsb, stream, da, w_ih, dx, B, T);
+        WM_CHECK_LAUNCH();
+        return 0;
+    }
     constexpr size_t lds = (size_t)(256 * 64 + 64 * 257) * sizeof(float);
     static bool done = false;
     if (!done) { WM_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_dx_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); done = true; }
-    const int ntiles = B * ((T + 63) / 64);
     hipLaunchKernelGGL(lstm_dx_kernel, dim3(ntiles < kNumCU ? ntiles : kNumCU), dim3(256), lds, stream, da, w_ih, dx, B, T);
     WM_CHECK_LAUNCH();
     return 0;

@@ -260,7 +260,7 @@ def main():
                 "config": {"workload": workload,
                            "batch_per_gpu": args.batch, "global_batch": args.batch * world, "clip_len": T,
                            "optimizer": "torch.optim.Adam" if args.torch_adam else "fused flat Adam (wm_adam_step)",
-                           "conv_arithmetic": "k3 convs fwd+dgrad: bf16x6 split on bf16 MFMA, fp32 accumulate (2.7e-7 vs fp64; native fp32 MFMA 2.5e-7)" if (args.model == "main16" and bf_mode) else "native fp32 MFMA",
+                           "conv_arithmetic": "64->64 convs (k3 and k7: fwd, dgrad, wgrad) and the LSTM input projection: bf16x6 split on bf16 MFMA, fp32 accumulate (2.7e-7 vs fp64; native fp32 MFMA 2.5e-7)" if (args.model == "main16" and bf_mode) else "native fp32 MFMA",
                            "parallelism": f"dp{world}" if world > 1 else "single"},
                 "loss": round(total_loss, 6), "roofline": roofline}
         if world == 1 and not args.no_cpu_baseline and args.model == "main16" and args.mode == "train":
