@@ -918,6 +918,132 @@ __global__ __launch_bounds__(256) void lstm_wgrad_kernel(const float* __restrict
     out[256 * 128 + tid] = bsum;
 }
 
+// ---------------------------------------------------------------------------------- wgrad GEMM, bf16x6
+// Same sums as lstm_wgrad_kernel on the bf16 matrix cores (bf16x6 split).  The contraction axis is time, the STRIDED
+// axis of da [t][n']: its A fragments (one gate column, 8 consecutive steps) are gathered from the [piece][step][n']
+// LDS image with eight ds_read_u16 per piece (lanes run along n': conflict-free) and packed with v_perm; z = [x ; h
+// shifted by one step] is time-contiguous, so its B fragments are aligned ds_read_b128.  32-step tiles; wave w owns the
+// gate columns [64 w, 64 w + 64) for all 128 z rows (128 accumulator registers).
+__global__ __launch_bounds__(256) void lstm_wgrad_bf_kernel(const float* __restrict__ da, const float* __restrict__ x,
+                                                            const float* __restrict__ h, float* __restrict__ partial,
+                                                            int B, int T) {
+    constexpr int NT = 32, NP = 3, PDD = 264, PZ = 40;
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    unsigned short* Dd = reinterpret_cast<unsigned short*>(smem_raw);          // [NP][NT][PDD]   da pieces, [step][n']
+    unsigned short* Zb = Dd + NP * NT * PDD;                                   // [NP][128][PZ]   z pieces, [row][step]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const int tilesPerClip = (T + NT - 1) / NT, ntiles = B * tilesPerClip;
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+    float bs[4] = {0.f, 0.f, 0.f, 0.f};            // bias sums of gate columns 4 (tid & 63) .. + 3 over this thread's steps
+    float4 sd[8], sx[2];
+    float sh[2][4];
+    // piece p: 0..7 da rows (step (tid >> 6) + 4 p, columns 4 (tid & 63)..), 8..9 x, 10..11 h (shifted: column tt = h[t0 + tt - 1])
+    auto load_piece = [&](int tile, int p) {
+        const int b = tile / tilesPerClip, t0 = (tile % tilesPerClip) * NT;
+        if (p < 8) {
+            const int t = min(t0 + (tid >> 6) + 4 * p, T - 1);
+            sd[p] = reinterpret_cast<const float4*>(da + ((size_t)b * T + t) * 256)[tid & 63];
+        } else {
+            const int k = p & 1, i = tid + k * 256, j = i >> 3, q = i & 7;
+            const size_t row = ((size_t)b * 64 + j) * T;
+            if (p < 10) sx[k] = *reinterpret_cast<const float4*>(x + row + min(t0 + 4 * q, T - 4));
+            else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) sh[k][e] = h[row + min(max(t0 + 4 * q + e - 1, 0), T - 1)];
+            }
+        }
+    };
+    auto put4 = [&](unsigned short* d, int stride_p, float v0, float v1, float v2, float v3) {
+        unsigned a0, a1, a2, b0, b1, b2;
+        split3_pair(v0, v1, a0, a1, a2);
+        split3_pair(v2, v3, b0, b1, b2);
+        *reinterpret_cast<uint2*>(d) = make_uint2(a0, b0);
+        *reinterpret_cast<uint2*>(d + stride_p) = make_uint2(a1, b1);
+        *reinterpret_cast<uint2*>(d + 2 * stride_p) = make_uint2(a2, b2);
+    };
+    auto write_tile = [&](int tile) {
+        const int t0 = (tile % tilesPerClip) * NT;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const int tt = (tid >> 6) + 4 * p;
+            float4 v = sd[p];
+            if (t0 + tt >= T) v = make_float4(0.f, 0.f, 0.f, 0.f);            // zero rows kill every product past T
+            bs[0] += v.x; bs[1] += v.y; bs[2] += v.z; bs[3] += v.w;
+            put4(Dd + tt * PDD + 4 * (tid & 63), NT * PDD, v.x, v.y, v.z, v.w);
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int i = tid + k * 256, j = i >> 3, q = i & 7;
+            put4(Zb + j * PZ + 4 * q, 128 * PZ, sx[k].x, sx[k].y, sx[k].z, sx[k].w);
+            float hv[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) hv[e] = (t0 + 4 * q + e - 1 >= 0) ? sh[k][e] : 0.f;      // zero initial state
+            put4(Zb + (64 + j) * PZ + 4 * q, 128 * PZ, hv[0], hv[1], hv[2], hv[3]);
+        }
+    };
+    int tile = blockIdx.x;
+#pragma unroll
+    for (int p = 0; p < 12; ++p) load_piece(min(tile, ntiles - 1), p);
+    __syncthreads();
+    write_tile(min(tile, ntiles - 1));
+    __syncthreads();
+    while (tile < ntiles) {
+        const int next = tile + gridDim.x, nextc = min(next, ntiles - 1);     // clamped: loaded (valid memory), never written
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            const int e0 = kb * 16 + 8 * half;
+            bf16x8 Bf[4][NP];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int p = 0; p < NP; ++p)
+                    Bf[nt][p] = *reinterpret_cast<const bf16x8*>(Zb + (p * 128 + nt * 32 + l31) * PZ + e0);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                bf16x8 A[NP];
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    const unsigned short* col = Dd + (p * NT + e0) * PDD + wave * 64 + mt * 32 + l31;
+                    unsigned w[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) w[j] = (unsigned)col[(2 * j) * PDD] | ((unsigned)col[(2 * j + 1) * PDD] << 16);
+                    A[p] = __builtin_bit_cast(bf16x8, make_uint4(w[0], w[1], w[2], w[3]));
+                }
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    acc[mt][nt] = mfma_bf16x6(A, Bf[nt], acc[mt][nt]);
+                    if ((kb * 2 + mt) * 4 + nt < 12) load_piece(nextc, (kb * 2 + mt) * 4 + nt);     // 12 pieces ride along the first 12 of 16 blocks
+                }
+            }
+        }
+        __syncthreads();
+        if (next < ntiles) write_tile(next);
+        __syncthreads();
+        tile = next;
+    }
+    float* out = partial + (size_t)blockIdx.x * (256 * 128 + 256);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                out[(wave * 64 + mt * 32 + mfma_row(r, half)) * 128 + nt * 32 + l31] = acc[mt][nt][r];
+    // bias: the four threads tid, tid + 64, .. share the gate columns 4 (tid & 63) .. + 3
+    float* red = reinterpret_cast<float*>(smem_raw);          // [4][256]
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[(tid >> 6) * 256 + 4 * (tid & 63) + e] = bs[e];
+    __syncthreads();
+    out[256 * 128 + tid] = (red[tid] + red[256 + tid]) + (red[512 + tid] + red[768 + tid]);
+}
+
 __global__ void lstm_wgrad_reduce_kernel(const float* __restrict__ partial, int nparts, float* dw_ih, float* dw_hh,
                                          float* db_ih, float* db_hh, int accumulate) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1022,12 +1148,22 @@ int wm_lstm_dx(const float* da, const float* w_ih, float* dx, int B, int T, hipS
 // partial: >= 256 * (256*128 + 256) floats
 int wm_lstm_wgrad(const float* da, const float* x, const float* h, float* partial, float* dw_ih, float* dw_hh,
                   float* db_ih, float* db_hh, int B, int T, int accumulate, hipStream_t stream) {
-    constexpr size_t lds = (size_t)(64 * 256 + 128 * 67) * sizeof(float);
-    static bool done = false;
-    if (!done) { WM_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); done = true; }
-    const int ntiles = B * ((T + 63) / 64);
-    const int grid = ntiles < kNumCU ? ntiles : kNumCU;
-    hipLaunchKernelGGL(lstm_wgrad_kernel, dim3(grid), dim3(256), lds, stream, da, x, h, partial, B, T);
+    int grid;
+    if (g_lstm_dx_bf) {                           // same switch as wm_lstm_dx: bf16x6 (default) | native fp32 MFMA
+        constexpr size_t ldsb = (size_t)(3 * 32 * 264 + 3 * 128 * 40) * 2;
+        static bool doneb = false;
+        if (!doneb) { WM_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_wgrad_bf_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb)); doneb = true; }
+        const int ntiles = B * ((T + 31) / 32);
+        grid = ntiles < kNumCU ? ntiles : kNumCU;
+        hipLaunchKernelGGL(lstm_wgrad_bf_kernel, dim3(grid), dim3(256), ldsb, stream, da, x, h, partial, B, T);
+    } else {
+        constexpr size_t lds = (size_t)(64 * 256 + 128 * 67) * sizeof(float);
+        static bool done = false;
+        if (!done) { WM_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); done = true; }
+        const int ntiles = B * ((T + 63) / 64);
+        grid = ntiles < kNumCU ? ntiles : kNumCU;
+        hipLaunchKernelGGL(lstm_wgrad_kernel, dim3(grid), dim3(256), lds, stream, da, x, h, partial, B, T);
+    }
     WM_CHECK_LAUNCH();
     constexpr int n = 256 * 128 + 256;
     hipLaunchKernelGGL(lstm_wgrad_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, (const float*)partial, grid,
