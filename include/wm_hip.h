@@ -119,7 +119,8 @@ int wm_lstm_fwd_fused(const float* x, const float* w_ih, const float* b_ih, cons
                       float* hout, float* gates, float* cst, int B, int T, wm_stream_t stream);
 int wm_lstm_bwd(float* gates, const float* cst, const float* dh_out, const float* w_hh, int B, int T, wm_stream_t stream);
 int wm_lstm_dx(const float* da, const float* w_ih, float* dx, int B, int T, wm_stream_t stream);
-/* arithmetic of wm_lstm_dx (process-wide): 1 bf16x6 split on the bf16 matrix cores (default, fp32-grade) | 0 native fp32 MFMA */
+/* arithmetic of wm_lstm_dx and wm_lstm_wgrad (process-wide): 1 bf16x6 split on the bf16 matrix cores (default,
+ * fp32-grade) | 0 native fp32 MFMA */
 int wm_set_lstm_dx_bf16x6(int on, wm_stream_t stream);
 /* wm_lstm_bwd + wm_lstm_dx in one launch: dx = da W_ih is formed chunk by chunk on the bf16 matrix cores (bf16x6 split)
  * beside the recurrence, from LDS -- no second pass over the [B,T,256] da tensor.  gates: activations in, da out. */

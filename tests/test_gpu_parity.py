@@ -569,6 +569,44 @@ def test_flat_adam_and_side_stream_wgrad(awm, dev):
     assert list(G2.state_dict().keys()) == list(gsd.keys())
 
 
+def test_full_size_properties_b256(awm, dev):
+    """BASELINE configs[2] size (B = 256 clips x 16 000 samples), checked through size-independent properties:
+    (1) eval mode: every clip of the big batch equals that clip run on its own (no cross-clip leakage in any tile /
+        workgroup mapping: persistent grids, XCD slots, deferred epilogues, fused LSTM chunks);
+    (2) train mode: the batch-statistic BatchNorms make the step permutation-equivariant over the clip axis --
+        permuting the batch permutes delta and leaves every loss term unchanged (up to fp32 summation order)."""
+    G, D, gsd, dsd = make_models(awm, dev)
+    B, T = 256, 16000
+    s = O.synthetic_clips(B, seed=123, T=T).to(dev)
+    msg = O.synthetic_messages(B, seed=124).to(dev)
+    G.eval(); D.eval()
+    pick = [0, 1, 97, 255]
+    with torch.no_grad():
+        d_all = awm.postprocess(G(s, msg))
+        lg_all = D(torch.cat([s + d_all, s], 0))
+        d_few = awm.postprocess(G(s[pick], msg[pick]))
+        lg_few = D(torch.cat([s[pick] + d_few, s[pick]], 0))
+    assert torch.equal(d_all[pick], d_few), float((d_all[pick] - d_few).abs().max())
+    idx = pick + [B + i for i in pick]
+    assert torch.equal(lg_all[idx], lg_few), float((lg_all[idx] - lg_few).abs().max())
+    assert torch.isfinite(lg_all).all()
+    # (2) permutation equivariance of the training-mode forward losses
+    G.train(); D.train()
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(5)).to(dev)
+    sd0 = {k: v.clone() for k, v in list(G.state_dict().items()) + [("D." + k, v) for k, v in D.state_dict().items()]}
+    with torch.no_grad():
+        _, out_a = awm.forward_losses(G, D, s, msg)
+        G.load_state_dict({k: v for k, v in sd0.items() if not k.startswith("D.")})          # undo the running-stat update
+        D.load_state_dict({k[2:]: v for k, v in sd0.items() if k.startswith("D.")})
+        _, out_b = awm.forward_losses(G, D, s[perm], msg[perm])
+    # fp32 summation order of the BatchNorm sums changes with the permutation: measured 5e-5 of max|delta|
+    assert float((out_b["delta"] - out_a["delta"][perm]).abs().max()) <= 3e-4 * float(out_a["delta"].abs().max())
+    for k in ("total", "loc", "bce", "l1", "mel", "loud", "hf"):
+        if k in out_a:
+            a, b = float(out_a[k]), float(out_b[k])
+            assert abs(a - b) <= 1e-4 * max(abs(a), abs(b), 1e-6) + 1e-7, (k, a, b)
+
+
 def test_file_level_embed_detect_batched(awm, dev):
     """N1: one batched call over all 1-s segments == the reference's per-segment B=1 loop (py/main16.py:996-1026,
     :1133-1164), incl. the zero-padded remainder segment and per-segment messages."""
