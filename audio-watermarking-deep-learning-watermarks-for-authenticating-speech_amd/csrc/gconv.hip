@@ -157,14 +157,18 @@ template <int KMAX>
 __global__ __launch_bounds__(256) void gwgrad_kernel(const float* __restrict__ A, const float* __restrict__ Bx,
                                                      float* __restrict__ G, float* __restrict__ dbias, int NB, int Ca, int Cb,
                                                      int La, int Lb, int K, int S, int P, int TC) {
-    // TC = positions per LDS chunk (multiple of 64, chosen by the launcher from the LDS budget: 256 / 128 / 64)
+    // Workgroup tile = 64 (a) x 64 (b); wave (ma, mb) owns one 32 x 32 block of it for every tap and walks the WHOLE
+    // chunk, so a staged element feeds two waves (the first version staged a 32 x 32 tile and split the chunk over the
+    // waves: twice the LDS traffic and four times the global traffic per MFMA).  TC = positions per LDS chunk (multiple of
+    // 64, chosen by the launcher so that two workgroups fit a CU: one stages while the other multiplies).
     extern __shared__ __align__(16) float smem[];
     const int BW = (TC - 1) * S + K;            // Bx span of a chunk
     const int AS = TC + 1, BS = BW | 1;         // odd strides: operands are read down a column
-    float* As = smem;                           // [32][AS]
-    float* Bs = smem + 32 * AS;                 // [32][BS]
+    float* As = smem;                           // [64][AS]
+    float* Bs = smem + 64 * AS;                 // [64][BS]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
-    const int a0 = blockIdx.x * 32, b0 = blockIdx.y * 32;
+    const int ma = wave & 1, mb = wave >> 1;
+    const int a0 = blockIdx.x * 64, b0 = blockIdx.y * 64;
     const int nchunks = (La + TC - 1) / TC, nwork = NB * nchunks;
     f32x16 acc[KMAX];
 #pragma unroll
@@ -177,44 +181,52 @@ __global__ __launch_bounds__(256) void gwgrad_kernel(const float* __restrict__ A
         const float* Ab = A + (size_t)nb * Ca * La;
         const float* Bb = Bx + (size_t)nb * Cb * Lb;
         __syncthreads();
-        for (int i = tid; i < 32 * TC; i += 256) {
-            const int r = i / TC, j = i - r * TC, a = a0 + r, t = t0 + j;
-            const float v = Ab[(size_t)min(a, Ca - 1) * La + min(t, La - 1)];
-            const float vv = (a < Ca && t < La) ? v : 0.f;
-            As[r * AS + j] = vv;
+        // staging: wave w copies rows w, w + 4, ...; lanes run along the position axis (coalesced, branch-free)
+        for (int r = wave; r < 64; r += 4) {
+            const int a = a0 + r;
+            const float* src = Ab + (size_t)min(a, Ca - 1) * La;
+            for (int j = lane; j < TC; j += 64) {
+                const int t = t0 + j;
+                const float v = src[min(t, La - 1)];
+                As[r * AS + j] = (a < Ca && t < La) ? v : 0.f;
+            }
         }
         const int u0 = t0 * S - P;
-        for (int i = tid; i < 32 * BW; i += 256) {
-            const int r = i / BW, j = i - r * BW, b = b0 + r, u = u0 + j;
-            const float v = Bb[(size_t)min(b, Cb - 1) * Lb + min(max(u, 0), Lb - 1)];
-            Bs[r * BS + j] = (b < Cb && u >= 0 && u < Lb) ? v : 0.f;
+        for (int r = wave; r < 64; r += 4) {
+            const int b = b0 + r;
+            const float* src = Bb + (size_t)min(b, Cb - 1) * Lb;
+            for (int j = lane; j < BW; j += 64) {
+                const int u = u0 + j;
+                const float v = src[min(max(u, 0), Lb - 1)];
+                Bs[r * BS + j] = (b < Cb && u >= 0 && u < Lb) ? v : 0.f;
+            }
         }
         __syncthreads();
-        // wave `wave` takes a quarter of the chunk: TC/8 k-steps of 2 positions
-        const int wq = TC / 4;
-        const float* ap = As + l31 * AS + wq * wave + half;
-        const float* bp = Bs + l31 * BS + (wq * wave + half) * S;
+        const float* ap = As + (ma * 32 + l31) * AS + half;
+        const float* bp = Bs + (mb * 32 + l31) * BS + half * S;
 #pragma unroll 4
-        for (int s = 0; s < wq / 2; ++s) {
+        for (int s = 0; s < TC / 2; ++s) {
             const float av = ap[2 * s];
 #pragma unroll
             for (int k = 0; k < KMAX; ++k)
                 if (k < K) acc[k] = mfma32(av, bp[2 * s * S + k], acc[k]);
         }
-        if (dbias && blockIdx.y == 0 && tid < 32)
-            for (int j = 0; j < TC; ++j) bsum += As[tid * AS + j];
+        if (dbias && blockIdx.y == 0) {          // row tid & 63, quarter tid >> 6 of the chunk
+            const float* rp = As + (tid & 63) * AS + (tid >> 6) * (TC / 4);
+            for (int j = 0; j < TC / 4; ++j) bsum += rp[j];
+        }
     }
 #pragma unroll
     for (int k = 0; k < KMAX; ++k) {
         if (k < K) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int a = a0 + mfma_row(r, half), b = b0 + l31;
+                const int a = a0 + ma * 32 + mfma_row(r, half), b = b0 + mb * 32 + l31;
                 if (a < Ca && b < Cb) atomicAdd(G + ((size_t)a * Cb + b) * K + k, acc[k][r]);
             }
         }
     }
-    if (dbias && blockIdx.y == 0 && tid < 32 && a0 + tid < Ca) atomicAdd(dbias + a0 + tid, bsum);
+    if (dbias && blockIdx.y == 0 && a0 + (tid & 63) < Ca) atomicAdd(dbias + a0 + (tid & 63), bsum);
 }
 
 // dz = g * elu'(y) with y = ELU(z):  elu'(z) = 1 for y > 0 else y + 1   (alpha = 1)
@@ -307,21 +319,23 @@ int wm_permute_acl(const float* x, float* y, int A, int C, int L, hipStream_t st
 int wm_gwgrad(const float* A, const float* Bx, float* G, float* dbias, int NB, int Ca, int Cb, int La, int Lb, int K, int S,
               int P, hipStream_t stream) {
     if (NB <= 0 || Ca <= 0 || Cb <= 0 || La <= 0 || K <= 0 || K > 16 || S <= 0 || S > 8) return (int)hipErrorInvalidValue;
-    int TC = 256;                                  // positions per LDS chunk, limited by a 90 KB LDS budget
-    while (TC > 64 && (size_t)(32 * (TC + 1) + 32 * (((TC - 1) * S + K) | 1)) * sizeof(float) > 90 * 1024) TC >>= 1;
+    int TC = 256;                                  // positions per LDS chunk: two workgroups of <= 78 KB per CU
+    auto lds_of = [&](int tc) { return (size_t)(64 * (tc + 1) + 64 * (((tc - 1) * S + K) | 1)) * sizeof(float); };
+    while (TC > 64 && lds_of(TC) > 78 * 1024) TC >>= 1;
     if (La <= 64) TC = 64;
     const int nchunks = (La + TC - 1) / TC, nwork = NB * nchunks;
-    const int tiles = ((Ca + 31) / 32) * ((Cb + 31) / 32);
-    int gz = (2048 + tiles - 1) / tiles;          // ~2048 workgroups in flight overall
+    const int tiles = ((Ca + 63) / 64) * ((Cb + 63) / 64);
+    int gz = (1024 + tiles - 1) / tiles;          // ~1024 workgroups in flight overall (2 per CU, twice over)
     if (gz > nwork) gz = nwork;
     if (gz < 1) gz = 1;
-    const size_t lds = (size_t)(32 * (TC + 1) + 32 * (((TC - 1) * S + K) | 1)) * sizeof(float);
-    dim3 grid((Ca + 31) / 32, (Cb + 31) / 32, gz);
+    const size_t lds = lds_of(TC);
+    if (lds > 150 * 1024) return (int)hipErrorInvalidValue;
+    dim3 grid((Ca + 63) / 64, (Cb + 63) / 64, gz);
     static bool done = false;
     if (!done) {
-        WM_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gwgrad_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-        WM_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gwgrad_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-        WM_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gwgrad_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        WM_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gwgrad_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        WM_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gwgrad_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        WM_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gwgrad_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         done = true;
     }
     if (K <= 4) hipLaunchKernelGGL(gwgrad_kernel<4>, grid, dim3(256), lds, stream, A, Bx, G, dbias, NB, Ca, Cb, La, Lb, K, S, P, TC);
