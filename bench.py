@@ -215,11 +215,11 @@ def main():
         flops_launch = 2.0 * 64 * 64 * 3 * T * clips_per_launch
         bytes_launch = 2.0 * 64 * T * 4 * clips_per_launch
         # HBM traffic of the dominant kernel from the committed PMC pass (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
-        # separate runs, gfx950 FETCH x2 correction; profiles/r01_pmc_fetch_write_b256_v7.json, profiles/summarize_pmc.py) -- same B=256 workload only
+        # separate runs, gfx950 FETCH x2 correction; profiles/r01_pmc_fetch_write_b256_v8.json, profiles/summarize_pmc.py) -- same B=256 workload only
         traffic = None
         try:
             if args.batch == 256:
-                pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_fetch_write_b256_v7.json")))["kernels"]
+                pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_fetch_write_b256_v8.json")))["kernels"]
                 pref = ("conv64bf3_kernel<0, 0", "conv64bf3_kernel<1, 0") if bf_mode else ("conv64_kernel<3, 256",)
                 ks = [v["hbm_bytes_per_launch_corrected"] for k, v in pm.items() if k.startswith(pref)]
                 traffic = sum(ks) / len(ks) if ks else None
