@@ -111,6 +111,9 @@ __device__ __forceinline__ T2 pk_fma_lanes(T2 w, float v, int k, T2 acc) {
     return acc;
 }
 
+#ifndef WM_LSTM_HS_BWD
+#define WM_LSTM_HS_BWD 64       // measured: 32 -> 7.84 ms, 48 -> 7.65 ms, 64 (no LDS round trip at all) -> 7.53 ms
+#endif
 #ifndef WM_LSTM_HS
 #define WM_LSTM_HS 32
 #endif
@@ -395,7 +398,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_fused_kernel(const float* __rest
 __global__ __launch_bounds__(256) void lstm_bwd_kernel(float* __restrict__ gates, const float* __restrict__ cst,
                                                        const float* __restrict__ dh_out, const float* __restrict__ w_hh,
                                                        int T) {
-    constexpr int HS = WM_LSTM_HS;
+    constexpr int HS = WM_LSTM_HS_BWD;
     __shared__ __align__(16) float das[4][64];      // wave-private da vectors
     __shared__ __align__(16) float part[2][64][4];  // [buffer][k][wave] partial dh
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -447,12 +450,14 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(float* __restrict__ gates
                 else da = dht * tc * go * (1.f - go);
                 dc = dct * gf;
                 gb[(size_t)t * 256] = da;
-                das[wave][lane] = da;                       // same wave reads it back: no barrier needed
-                __builtin_amdgcn_wave_barrier();
+                if (HS < 64) {
+                    das[wave][lane] = da;                   // same wave reads it back: no barrier needed
+                    __builtin_amdgcn_wave_barrier();
+                }
                 // the wave's own 64 da values: the first HS straight out of the register (v_readlane -> SGPR-pair FMA
                 // operands), the rest as broadcast LDS reads -- VALU and the LDS return path share the load (see lstm_fwd)
                 const float4* dp = reinterpret_cast<const float4*>(das[wave]);
-                float4 dq[(64 - HS) / 4];
+                float4 dq[HS < 64 ? (64 - HS) / 4 : 1];
 #pragma unroll
                 for (int k = 0; k < (64 - HS) / 4; ++k) dq[k] = dp[HS / 4 + k];
                 v2f a01 = v2f{0.f, 0.f}, a23 = a01;
