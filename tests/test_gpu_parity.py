@@ -569,6 +569,52 @@ def test_flat_adam_and_side_stream_wgrad(awm, dev):
     assert list(G2.state_dict().keys()) == list(gsd.keys())
 
 
+@pytest.mark.parametrize("training", [False, True])
+def test_default_constructor_no_message_bits(awm, dev, training):
+    """the reference's DEFAULT constructors, Generator(message_bits=0) / Detector(message_bits=0) (py/main16.py:129,171):
+    no embedding table, a one-channel Detector head -- forward and every gradient against the oracle"""
+    torch.manual_seed(7)
+    G, D = awm.Generator(), awm.Detector()
+    assert not hasattr(G, "embedding") and G.message_bits == 0 and D.model[3].weight.shape == (1, 64, 1)
+    gsd = {k: v.clone() for k, v in G.state_dict().items()}
+    dsd = {k: v.clone() for k, v in D.state_dict().items()}
+    G.to(dev).train(training); D.to(dev).train(training)
+    B, T = 2, 1280
+    s = O.synthetic_clips(B, seed=77, T=T)
+    wgt = rnd(2 * B, T, 1, seed=78)
+
+    def oracle_run(dtype):
+        def leaf(k, v):
+            if not v.is_floating_point():
+                return v.clone()
+            w = v.detach().to(dtype).clone()
+            return w if "running" in k else w.requires_grad_()
+        gs = {k: leaf(k, v) for k, v in gsd.items()}
+        ds = {k: leaf(k, v) for k, v in dsd.items()}
+        sd_ = s.to(dtype)
+        d_ = O.generator_forward(gs, sd_, None, training=training, message_bits=0, new_stats={})
+        lg_ = O.detector_forward(ds, torch.cat([sd_ + d_, sd_], 0), training=training, new_stats={})
+        (lg_ * wgt.to(dtype)).sum().backward()
+        return d_.detach(), lg_.detach(), gs, ds
+
+    d_ref, lg_ref, gs32, ds32 = oracle_run(torch.float32)
+    _, _, gs64, ds64 = oracle_run(torch.float64)           # truth for the gradients (whole-network fp32 gradients are noisy)
+    d = G(s.to(dev))
+    lg = D(torch.cat([s.to(dev) + d, s.to(dev)], 0))
+    assert lg.shape == (2 * B, T, 1)
+    check(d, d_ref, FWD_TOL, "delta (bits = 0)")
+    check(lg, lg_ref, FWD_TOL, "logits (bits = 0)")
+    (lg * wgt.to(dev)).sum().backward()
+    for name, mod, r32, r64 in (("G", G, gs32, gs64), ("D", D, ds32, ds64)):
+        for k, prm in mod.named_parameters():
+            if training and (k.endswith("block.0.bias") or k.endswith("block.3.bias")):
+                continue                                   # exactly-zero true gradient in front of a batch-stat BN
+            truth = r64[k].grad
+            e_hip = rel_err(prm.grad.double().cpu(), truth)
+            e_cpu = rel_err(r32[k].grad.double(), truth)
+            assert e_hip <= max(5e-3, 8.0 * e_cpu), f"{name}.{k} grad (bits = 0): {e_hip:.2e} vs fp64 (CPU fp32: {e_cpu:.2e})"
+
+
 def test_full_size_properties_b256(awm, dev):
     """BASELINE configs[2] size (B = 256 clips x 16 000 samples), checked through size-independent properties:
     (1) eval mode: every clip of the big batch equals that clip run on its own (no cross-clip leakage in any tile /
