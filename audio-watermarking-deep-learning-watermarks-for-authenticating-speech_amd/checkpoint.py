@@ -51,17 +51,21 @@ def load_resumable(path, generator, detector, optimizer=None, scheduler=None, ma
 
 
 def _opt_state(opt):
+    """`optimizer.state_dict()` (py/main14d.py:547): optim.FlatAdam emits torch.optim.Adam's layout, tensors on the CPU"""
     if opt is None:
         return None
-    if hasattr(opt, "flat"):       # optim.FlatAdam
-        return {"flat_adam": True, "m": opt.m.detach().cpu(), "v": opt.v.detach().cpu(), "t": opt.t, "lr": opt.lr}
-    return opt.state_dict()
+    sd = opt.state_dict()
+    for st in sd.get("state", {}).values():
+        for k, v in st.items():
+            if torch.is_tensor(v):
+                st[k] = v.detach().cpu()
+    return sd
 
 
 def _load_opt_state(opt, state):
-    if hasattr(opt, "flat"):
-        if not state.get("flat_adam"):
-            raise ValueError("checkpoint holds a torch.optim state, the optimizer is a FlatAdam")
+    if state.get("flat_adam"):          # round-1 private schema {flat_adam, m, v, t, lr}: still readable
+        if not hasattr(opt, "flat"):
+            raise ValueError("checkpoint holds a round-1 FlatAdam state, the optimizer is not a FlatAdam")
         opt.m.copy_(state["m"]); opt.v.copy_(state["v"]); opt.t = int(state["t"]); opt.lr = float(state["lr"])
-    else:
-        opt.load_state_dict(state)
+        return
+    opt.load_state_dict(state)

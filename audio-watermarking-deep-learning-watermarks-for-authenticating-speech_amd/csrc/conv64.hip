@@ -281,11 +281,11 @@ __global__ __launch_bounds__(256) void conv64_kernel(Conv64Args a) {
 template <int KW, int NT, int PRO, int EPI, bool STATS>
 int launch_conv64(const Conv64Args& a, hipStream_t stream) {
     constexpr size_t lds = (size_t)(KW * 4096 + 64 * (NT + 8) + 6 * 64) * sizeof(float);
-    static bool attr_done = false;
+    static wm::DevOnce attr_done;
     auto kern = conv64_kernel<KW, NT, PRO, EPI, STATS>;
-    if (!attr_done) {
+    if (!wm::dev_done(attr_done)) {
         WM_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_done = true;
+        wm::dev_mark(attr_done);
     }
     const int ntiles = a.B * ((a.T + NT - 1) / NT);
     const int grid = ntiles < kNumCU ? ntiles : kNumCU;
@@ -521,11 +521,11 @@ template <int KW, int GPRO, int XPRO>
 int launch_wgrad64(const Wgrad64Args& a, int* grid_out, hipStream_t stream) {
     constexpr int NT = 128;
     constexpr size_t lds = (size_t)(64 * (NT + 4) + 64 * (NT + 8) + 6 * 64) * sizeof(float);
-    static bool attr_done = false;
+    static wm::DevOnce attr_done;
     auto kern = wgrad64_kernel<KW, GPRO, XPRO>;
-    if (!attr_done) {
+    if (!wm::dev_done(attr_done)) {
         WM_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_done = true;
+        wm::dev_mark(attr_done);
     }
     const int ntiles = a.B * ((a.T + NT - 1) / NT);
     const int grid = ntiles < kNumCU ? ntiles : kNumCU;
@@ -802,11 +802,11 @@ __global__ __launch_bounds__(256) void conv64bf_kernel(Conv64Args a) {
 template <int PRO, int EPI, bool STATS>
 int launch_conv64bf(const Conv64Args& a, hipStream_t stream) {
     constexpr size_t lds = (size_t)(3 * 3 * 64 * 72 + 3 * 130 * 72) * 2 + 6 * 64 * sizeof(float);
-    static bool attr_done = false;
+    static wm::DevOnce attr_done;
     auto kern = conv64bf_kernel<PRO, EPI, STATS>;
-    if (!attr_done) {
+    if (!wm::dev_done(attr_done)) {
         WM_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_done = true;
+        wm::dev_mark(attr_done);
     }
     const int ntiles = a.B * ((a.T + 127) / 128);
     const int grid = ntiles < kNumCU ? ntiles : kNumCU;
@@ -1126,11 +1126,11 @@ __global__ __launch_bounds__(256) void conv64bf3_kernel(Conv64Args a) {
 template <int PRO, int EPI, bool STATS>
 int launch_conv64bf3(const Conv64Args& a, hipStream_t stream) {
     constexpr size_t lds = (size_t)(2 * 3 * 130 * 72) * 2 + 6 * 64 * sizeof(float);
-    static bool attr_done = false;
+    static wm::DevOnce attr_done;
     auto kern = conv64bf3_kernel<PRO, EPI, STATS>;
-    if (!attr_done) {
+    if (!wm::dev_done(attr_done)) {
         WM_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_done = true;
+        wm::dev_mark(attr_done);
     }
     const int ntiles = a.B * ((a.T + 127) / 128);
     const int grid = ntiles < kNumCU ? ntiles : kNumCU;
@@ -1347,11 +1347,11 @@ __global__ __launch_bounds__(512, 2) void conv64bf2_kernel(Conv64Args a) {
 template <int PRO, int EPI, bool STATS>
 int launch_conv64bf2(const Conv64Args& a, hipStream_t stream) {
     constexpr size_t lds = (size_t)(3 * 3 * 64 * 72 + 2 * 3 * 66 * 72) * 2 + (6 * 64 + 8 * 128) * sizeof(float);
-    static bool attr_done = false;
+    static wm::DevOnce attr_done;
     auto kern = conv64bf2_kernel<PRO, EPI, STATS>;
-    if (!attr_done) {
+    if (!wm::dev_done(attr_done)) {
         WM_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_done = true;
+        wm::dev_mark(attr_done);
     }
     const int ntiles = a.B * ((a.T + 63) / 64);
     int grid = (ntiles + 1) / 2;
@@ -1515,11 +1515,11 @@ __global__ __launch_bounds__(256) void conv64bf7_kernel(Conv64Args a) {
 template <int PRO, int EPI>
 int launch_conv64bf7(const Conv64Args& a, hipStream_t stream) {
     constexpr size_t lds = (size_t)(3 * 7 * 32 * 72 + 3 * 134 * 72) * 2 + 32 * sizeof(float);
-    static bool attr_done = false;
+    static wm::DevOnce attr_done;
     auto kern = conv64bf7_kernel<PRO, EPI>;
-    if (!attr_done) {
+    if (!wm::dev_done(attr_done)) {
         WM_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_done = true;
+        wm::dev_mark(attr_done);
     }
     const int ntiles = a.B * ((a.T + 127) / 128);
     const int grid = 2 * (ntiles < kNumCU / 2 ? ntiles : kNumCU / 2);
@@ -1748,11 +1748,11 @@ __global__ __launch_bounds__(256) void wgrad64bf_kernel(Wgrad64Args a) {
 template <int GPRO, int XPRO>
 int launch_wgrad64bf(const Wgrad64Args& a, int* grid_out, hipStream_t stream) {
     constexpr size_t lds = (size_t)(3 * 64 * 136 + 3 * 64 * 152) * 2 + 6 * 64 * sizeof(float);
-    static bool attr_done = false;
+    static wm::DevOnce attr_done;
     auto kern = wgrad64bf_kernel<GPRO, XPRO>;
-    if (!attr_done) {
+    if (!wm::dev_done(attr_done)) {
         WM_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_done = true;
+        wm::dev_mark(attr_done);
     }
     const int ntiles = a.B * ((a.T + 127) / 128);
     const int grid = ntiles < kNumCU ? ntiles : kNumCU;
@@ -1926,11 +1926,11 @@ __global__ __launch_bounds__(256) void wgrad64bf7_kernel(Wgrad64Args a) {
 template <int XPRO>
 int launch_wgrad64bf7(const Wgrad64Args& a, int* grid_out, hipStream_t stream) {
     constexpr size_t lds = (size_t)(3 * 64 * 136 + 3 * 64 * 152) * 2;
-    static bool attr_done = false;
+    static wm::DevOnce attr_done;
     auto kern = wgrad64bf7_kernel<XPRO>;
-    if (!attr_done) {
+    if (!wm::dev_done(attr_done)) {
         WM_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_done = true;
+        wm::dev_mark(attr_done);
     }
     const int ntiles = a.B * ((a.T + 127) / 128);
     const int grid = ntiles < kNumCU ? ntiles : kNumCU;

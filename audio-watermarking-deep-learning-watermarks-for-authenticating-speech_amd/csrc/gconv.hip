@@ -331,12 +331,12 @@ int wm_gwgrad(const float* A, const float* Bx, float* G, float* dbias, int NB, i
     const size_t lds = lds_of(TC);
     if (lds > 150 * 1024) return (int)hipErrorInvalidValue;
     dim3 grid((Ca + 63) / 64, (Cb + 63) / 64, gz);
-    static bool done = false;
-    if (!done) {
+    static wm::DevOnce done;
+    if (!wm::dev_done(done)) {
         WM_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gwgrad_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         WM_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gwgrad_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         WM_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gwgrad_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        done = true;
+        wm::dev_mark(done);
     }
     if (K <= 4) hipLaunchKernelGGL(gwgrad_kernel<4>, grid, dim3(256), lds, stream, A, Bx, G, dbias, NB, Ca, Cb, La, Lb, K, S, P, TC);
     else if (K <= 8) hipLaunchKernelGGL(gwgrad_kernel<8>, grid, dim3(256), lds, stream, A, Bx, G, dbias, NB, Ca, Cb, La, Lb, K, S, P, TC);

@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256) void sum_scale2_kernel(const float* __restrict
 // Adam over one flat fp32 span (torch.optim.Adam defaults semantics, py/main16.py:504): no amsgrad,
 // weight_decay 0, bias correction from the step count.
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                            size_t n, float lr, float b1, float b2, float eps, float bc1, float bc2_sqrt) {
+                            size_t n, float step_size, float b1, float b2, float eps, float bc2_sqrt) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float gi = g[i];
@@ -114,7 +114,7 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
     const float vi = fmaf(b2, v[i], (1.f - b2) * gi * gi);
     m[i] = mi; v[i] = vi;
     const float denom = sqrtf(vi) / bc2_sqrt + eps;
-    p[i] -= (lr / bc1) * (mi / denom);
+    p[i] -= step_size * (mi / denom);
 }
 
 }  // namespace
@@ -164,12 +164,15 @@ int wm_l1_bwd(const float* x, const float* g, float* dx, long long n, hipStream_
 }
 
 // one Adam update over a flat span; step >= 1 is the 1-based update count
-int wm_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,
+// (the bias corrections are formed in double on the host, as torch.optim.Adam does, and handed over rounded once)
+int wm_adam_step(float* p, const float* g, float* m, float* v, long long n, double lr, double beta1, double beta2, double eps,
                  int step, hipStream_t stream) {
-    const float bc1 = 1.f - powf(beta1, (float)step);
-    const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
-    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, p, g, m, v, (size_t)n, lr, beta1,
-                       beta2, eps, bc1, bc2s);
+    if (step < 1 || n < 0) return (int)hipErrorInvalidValue;
+    if (n == 0) return 0;
+    const double bc1 = 1.0 - pow(beta1, (double)step);
+    const double bc2s = sqrt(1.0 - pow(beta2, (double)step));
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, p, g, m, v, (size_t)n,
+                       (float)(lr / bc1), (float)beta1, (float)beta2, (float)eps, (float)bc2s);
     WM_CHECK_LAUNCH();
     return 0;
 }

@@ -1095,11 +1095,11 @@ int wm_lstm_fwd_fused(const float* x, const float* w_ih, const float* b_ih, cons
                       float* gates, float* cst, int B, int T, hipStream_t stream) {
     if ((T & 3) || T < 8) return (int)hipErrorInvalidValue;
     constexpr size_t lds = (size_t)2 * 32 * 257 * sizeof(float) + (size_t)3 * 32 * 72 * 2 + 128 * sizeof(float);
-    static bool done = false;
-    if (!done) {
+    static wm::DevOnce done;
+    if (!wm::dev_done(done)) {
         WM_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_fwd_fused_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         WM_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_fwd_fused_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        done = true;
+        wm::dev_mark(done);
     }
     if (gates && cst) hipLaunchKernelGGL(lstm_fwd_fused_kernel<true>, dim3(B), dim3(256), lds, stream, x, w_ih, b_ih, b_hh, w_hh, hout, gates, cst, T);
     else hipLaunchKernelGGL(lstm_fwd_fused_kernel<false>, dim3(B), dim3(256), lds, stream, x, w_ih, b_ih, b_hh, w_hh, hout, gates, cst, T);
@@ -1119,10 +1119,10 @@ int wm_lstm_bwd_fused(float* gates, const float* cst, const float* dh_out, const
                       int B, int T, hipStream_t stream) {
     if ((T & 3) || T < 4) return (int)hipErrorInvalidValue;
     constexpr size_t lds = (size_t)2 * 4 * 3 * 32 * 72 * 2 + (size_t)(4 * 64 * 33 + 4 * 64 + 2 * 64 * 4) * sizeof(float);
-    static bool done = false;
-    if (!done) {
+    static wm::DevOnce done;
+    if (!wm::dev_done(done)) {
         WM_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_bwd_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        done = true;
+        wm::dev_mark(done);
     }
     hipLaunchKernelGGL(lstm_bwd_fused_kernel, dim3(B), dim3(256), lds, stream, gates, cst, dh_out, w_hh, w_ih, dx, T);
     WM_CHECK_LAUNCH();
@@ -1136,15 +1136,15 @@ int wm_lstm_dx(const float* da, const float* w_ih, float* dx, int B, int T, hipS
     const int ntiles = B * ((T + 63) / 64);
     if (g_lstm_dx_bf) {
         constexpr size_t ldsb = (size_t)3 * 64 * 264 * 2;
-        static bool doneb = false;
-        if (!doneb) { WM_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_dx_bf_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb)); doneb = true; }
+        static wm::DevOnce doneb;
+        if (!wm::dev_done(doneb)) { WM_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_dx_bf_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb)); wm::dev_mark(doneb); }
         hipLaunchKernelGGL(lstm_dx_bf_kernel, dim3(ntiles < kNumCU ? ntiles : kNumCU), dim3(256), ldsb, stream, da, w_ih, dx, B, T);
         WM_CHECK_LAUNCH();
         return 0;
     }
     constexpr size_t lds = (size_t)(256 * 64 + 64 * 257) * sizeof(float);
-    static bool done = false;
-    if (!done) { WM_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_dx_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); done = true; }
+    static wm::DevOnce done;
+    if (!wm::dev_done(done)) { WM_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_dx_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); wm::dev_mark(done); }
     hipLaunchKernelGGL(lstm_dx_kernel, dim3(ntiles < kNumCU ? ntiles : kNumCU), dim3(256), lds, stream, da, w_ih, dx, B, T);
     WM_CHECK_LAUNCH();
     return 0;
@@ -1156,15 +1156,15 @@ int wm_lstm_wgrad(const float* da, const float* x, const float* h, float* partia
     int grid;
     if (g_lstm_dx_bf) {                           // same switch as wm_lstm_dx: bf16x6 (default) | native fp32 MFMA
         constexpr size_t ldsb = (size_t)(3 * 32 * 264 + 3 * 128 * 40) * 2;
-        static bool doneb = false;
-        if (!doneb) { WM_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_wgrad_bf_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb)); doneb = true; }
+        static wm::DevOnce doneb;
+        if (!wm::dev_done(doneb)) { WM_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_wgrad_bf_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb)); wm::dev_mark(doneb); }
         const int ntiles = B * ((T + 31) / 32);
         grid = ntiles < kNumCU ? ntiles : kNumCU;
         hipLaunchKernelGGL(lstm_wgrad_bf_kernel, dim3(grid), dim3(256), ldsb, stream, da, x, h, partial, B, T);
     } else {
         constexpr size_t lds = (size_t)(64 * 256 + 128 * 67) * sizeof(float);
-        static bool done = false;
-        if (!done) { WM_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); done = true; }
+        static wm::DevOnce done;
+        if (!wm::dev_done(done)) { WM_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); wm::dev_mark(done); }
         const int ntiles = B * ((T + 63) / 64);
         grid = ntiles < kNumCU ? ntiles : kNumCU;
         hipLaunchKernelGGL(lstm_wgrad_kernel, dim3(grid), dim3(256), lds, stream, da, x, h, partial, B, T);

@@ -477,10 +477,10 @@ int wm_stem_bwd(const float* g, const float* s, const float* w, float* ds, float
                 int T, int nds, int accumulate, hipStream_t stream) {
     if (T & 3) return (int)hipErrorInvalidValue;
     constexpr size_t lds = (size_t)(64 * 264 + 296 + 512 + 4 * 256) * sizeof(float);
-    static bool attr_done = false;
-    if (!attr_done) {
+    static wm::DevOnce attr_done;
+    if (!wm::dev_done(attr_done)) {
         WM_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(stem_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_done = true;
+        wm::dev_mark(attr_done);
     }
     const int ntiles = B * ((T + 255) / 256);
     const int grid = ntiles < kNumCU ? ntiles : kNumCU;
@@ -532,12 +532,12 @@ int wm_headN_bwd(const float* g, const float* x, const float* w, float* dx, floa
     const int grid = ntiles < kNumCU ? ntiles : kNumCU;
     const size_t lds = (size_t)(64 * 257 + 256 * 33 + 32 * 64) * sizeof(float);
     if (NO == 17) {
-        static bool done = false;
-        if (!done) { WM_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(headN_bwd_kernel<17>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); done = true; }
+        static wm::DevOnce done;
+        if (!wm::dev_done(done)) { WM_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(headN_bwd_kernel<17>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); wm::dev_mark(done); }
         hipLaunchKernelGGL(headN_bwd_kernel<17>, dim3(grid), dim3(256), lds, stream, g, x, w, dx, partial, B, T);
     } else if (NO == 1) {
-        static bool done = false;
-        if (!done) { WM_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(headN_bwd_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); done = true; }
+        static wm::DevOnce done;
+        if (!wm::dev_done(done)) { WM_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(headN_bwd_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); wm::dev_mark(done); }
         hipLaunchKernelGGL(headN_bwd_kernel<1>, dim3(grid), dim3(256), lds, stream, g, x, w, dx, partial, B, T);
     } else return (int)hipErrorInvalidValue;
     WM_CHECK_LAUNCH();

@@ -3,11 +3,29 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 
 #define WM_CHECK_LAUNCH() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)
 #define WM_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return (int)e_; } while (0)
 
 namespace wm {
+
+// hipFuncSetAttribute (the > 64 KB dynamic-LDS opt-in) is a PER-DEVICE setting: remember it per device ordinal, so one
+// process may drive several GPUs (and several host threads: the attribute call is idempotent, a race only repeats it).
+// The only mutable state the launchers keep is this cache.
+struct DevOnce {
+    std::atomic<unsigned long long> mask{0};
+};
+inline bool dev_done(const DevOnce& d) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    return (d.mask.load(std::memory_order_acquire) >> (dev & 63)) & 1ull;
+}
+inline void dev_mark(DevOnce& d) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return;
+    d.mask.fetch_or(1ull << (dev & 63), std::memory_order_release);
+}
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));

@@ -111,30 +111,32 @@ def generate_watermarked_audio(input_file, generator, output_file=None, message_
 
 @torch.no_grad()
 def detect_waveform(waveform, detector, detection_threshold=0.5, device="cuda", max_batch=512):
-    """detect_watermark (:1114-1207) on an in-memory waveform, batched; same result dict (no plotting)."""
+    """detect_watermark (:1114-1207) on an in-memory waveform, batched; same result dict (no plotting).  The
+    per-segment reductions run on the device: only the temporal probability track the reference returns ((N,) floats)
+    and 1+bits scalars cross to the host, never the [S,T,1+bits] logits."""
     detector.eval()
     segs, remainder = _segments(waveform.float())
     S = segs.shape[0]
-    probs, msg_logits = [], []
+    n = waveform.shape[1]
+    bits = int(getattr(detector, "message_bits", 0))
+    probs, seg_logit_means = [], []
     for i in range(0, S, max_batch):
         logits = detector(segs[i:i + max_batch].to(device))            # [s,T,1+bits]
-        probs.append(torch.sigmoid(logits[:, :, 0]).cpu())
-        if getattr(detector, "message_bits", 0) > 0:
-            msg_logits.append(logits[:, :, 1:].cpu())
-    probs = torch.cat(probs, dim=0)                                     # [S,T]
-    n = waveform.shape[1]
-    temporal = probs.reshape(-1)[:n]
+        probs.append(torch.sigmoid(logits[:, :, 0]))
+        if bits > 0:
+            ml = logits[:, :, 1:]
+            last = (i + ml.shape[0] == S) and remainder > 0
+            m = ml.mean(dim=1)                                          # per-segment mean over its samples (:1142)
+            if last:                                                    # the remainder segment: valid samples only (:1162)
+                m = torch.cat([m[:-1], ml[-1, :remainder].mean(dim=0, keepdim=True)], dim=0)
+            seg_logit_means.append(m)
+    temporal = torch.cat(probs, dim=0).reshape(-1)[:n]                  # [N] on the device
     mean_prob = temporal.mean().item()
     is_wm = mean_prob > detection_threshold
-    result = {"mean_probability": mean_prob, "is_watermarked": is_wm, "temporal_probs": temporal.numpy(),
+    result = {"mean_probability": mean_prob, "is_watermarked": is_wm, "temporal_probs": temporal.cpu().numpy(),
               "decision": "WATERMARKED" if is_wm else "NOT WATERMARKED"}
-    if msg_logits:
-        ml = torch.cat(msg_logits, dim=0)                               # [S,T,bits]
-        per_seg = []
-        for k in range(S):                                              # per-segment mean over its valid samples (:1142,:1162)
-            valid = remainder if (remainder > 0 and k == S - 1) else ml.shape[1]
-            per_seg.append(ml[k, :valid].mean(dim=0))
-        mean_logits = torch.stack(per_seg).mean(dim=0)
+    if seg_logit_means:
+        mean_logits = torch.cat(seg_logit_means, dim=0).mean(dim=0)
         result["predicted_message"] = (mean_logits > 0).int().tolist()
         result["message_confidence"] = torch.sigmoid(mean_logits).tolist()
     return result
@@ -146,18 +148,85 @@ def detect_watermark(input_file, detector, detection_threshold=0.5, visualize=Fa
 
 
 @torch.no_grad()
-def evaluate_batches(generator, detector, batches, device="cuda", message_bits=16, threshold=0.5):
-    """evaluate_model (:369-423): the per-batch reductions run on the device (step.eval_forward), only four scalars
-    per batch come back to the host."""
+def detect_prob(file_path, detector, sample_rate=SAMPLE_RATE, device="cuda", max_batch=512):
+    """py/main16.py:1575-1596: average over the file's 1-s segments of each segment's mean detection probability.  The
+    mean of a segment runs over all 16 000 samples of the zero-PADDED tail segment too (unlike detect_watermark, which
+    trims it), so this is a mean of per-segment means, not the mean of the temporal track.  One batched Detector call;
+    accepts a path or an in-memory (1,N) waveform."""
+    waveform = load_audio(file_path, sample_rate) if isinstance(file_path, (str, os.PathLike)) else file_path
+    segs, _ = _segments(waveform.float(), sample_rate)
+    if segs.shape[0] == 0:
+        return float("nan")                                             # np.mean([]) in the reference
+    seg_means = []
+    for i in range(0, segs.shape[0], max_batch):
+        logits = detector(segs[i:i + max_batch].to(device))
+        seg_means.append(torch.sigmoid(logits[:, :, 0]).mean(dim=1))
+    return float(torch.cat(seg_means).double().mean().item())
+
+
+def _si_snr_rows(s, s_hat, eps=1e-8):
+    """compute_si_snr (:764-773) applied to each (1,1,T) segment of a [S,1,T] batch, as evaluate_unseen_file does
+    (:1294): the reductions run over dim=1 -- for a 3-D segment that is the size-1 CHANNEL axis, so s - mean == 0 and
+    every segment yields 10*log10(0/eps) = -inf.  Kept as is (reference quirk; call compute_si_snr on (1,N) waveforms
+    for a meaningful value).  Returns [S] per-segment values."""
+    s = s - s.mean(dim=1, keepdim=True)
+    s_hat = s_hat - s_hat.mean(dim=1, keepdim=True)
+    dot = torch.sum(s * s_hat, dim=1, keepdim=True)
+    alpha = dot / (torch.sum(s ** 2, dim=1, keepdim=True) + eps)
+    s_target = alpha * s
+    e_noise = s_hat - s_target
+    return (10 * torch.log10(torch.sum(s_target ** 2, dim=1) / (torch.sum(e_noise ** 2, dim=1) + eps))).mean(dim=1)
+
+
+@torch.no_grad()
+def evaluate_unseen_file(filepath, generator, detector, device="cuda", message_bits=16, messages=None, max_batch=256):
+    """py/main16.py:1263-1299 with all 1-s segments of the file as one batch: returns (mean clean detection probability,
+    mean watermarked detection probability, mean SI-SNR, mean delta RMS) over the segments, or four Nones when the file
+    cannot be read (:1264-1267).  A fresh random message per segment (:1287) unless `messages` is given.  Accepts a path
+    or an in-memory (1,N) waveform.  Per-segment reductions run on the device; four scalars come back."""
+    if isinstance(filepath, (str, os.PathLike)):
+        try:
+            waveform = load_audio(filepath)
+        except Exception:
+            return None, None, None, None
+    else:
+        waveform = filepath
+    generator.eval(); detector.eval()
+    segs, _ = _segments(waveform.float())
+    S = segs.shape[0]
+    if S == 0:
+        return (float("nan"),) * 4
+    if messages is None:
+        messages = torch.randint(0, 2 ** message_bits, (S,), device=device)
+    clean, wm, si, rms = [], [], [], []
+    for i in range(0, S, max_batch):
+        seg = segs[i:i + max_batch].to(device)
+        delta = generator(seg, messages[i:i + max_batch].to(device))
+        seg_w = seg + delta
+        p = torch.sigmoid(detector(torch.cat([seg, seg_w], dim=0))[:, :, 0]).mean(dim=1)    # eval-mode BN: rows independent
+        k = seg.shape[0]
+        clean.append(p[:k]); wm.append(p[k:])
+        rms.append(torch.sqrt((delta ** 2).mean(dim=[1, 2])))
+        si.append(_si_snr_rows(seg, seg_w))
+    out = torch.stack([torch.cat(v).double().mean() for v in (clean, wm, si, rms)]).cpu()
+    return tuple(float(v) for v in out)
+
+
+@torch.no_grad()
+def evaluate_batches(generator, detector, batches, device="cuda", message_bits=16, threshold=0.5, messages=None):
+    """evaluate_model (:369-423): the per-batch reductions run on the device (step.eval_forward); the per-clip values of
+    all batches are pooled and averaged once, as the reference's np.mean over its extended lists does (so a ragged last
+    batch weighs by its clips).  `messages` (optional list, one tensor per batch) replaces the randint draw of :381."""
     from .step import eval_forward
     generator.eval(); detector.eval()
-    acc = {"watermarked_prob": [], "clean_prob": [], "bit_accuracy": [], "delta_rms": []}
-    for s in batches:
+    keys = {"watermarked_prob": "prob_watermarked", "clean_prob": "prob_clean", "bit_accuracy": "bit_accuracy",
+            "delta_rms": "delta_rms"}
+    acc = {k: [] for k in keys}
+    for bi, s in enumerate(batches):
         s = s.to(device)
-        message = torch.randint(0, 2 ** message_bits, (s.shape[0],), device=device)
+        message = (messages[bi].to(device) if messages is not None else
+                   torch.randint(0, 2 ** message_bits, (s.shape[0],), device=device))
         out = eval_forward(generator, detector, s, message)
-        acc["watermarked_prob"].append(out["prob_watermarked"].mean())
-        acc["clean_prob"].append(out["prob_clean"].mean())
-        acc["bit_accuracy"].append(out["bit_accuracy"].mean())
-        acc["delta_rms"].append(out["delta_rms"].mean())
-    return {k: float(torch.stack(v).mean()) if v else math.nan for k, v in acc.items()}
+        for k, src in keys.items():
+            acc[k].append(out[src])
+    return {k: float(torch.cat(v).double().mean()) if v else math.nan for k, v in acc.items()}

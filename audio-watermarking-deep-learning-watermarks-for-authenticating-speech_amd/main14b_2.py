@@ -151,6 +151,8 @@ class RowsGatherFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, table, idx):
+        if ops._CHECK_INDEX["on"] and bool(((idx < 0) | (idx >= table.shape[0])).any().item()):
+            raise IndexError(f"message id out of range for an embedding table of {table.shape[0]} rows")   # nn.Embedding
         ctx.save_for_backward(idx)
         ctx.shape = table.shape
         return table.index_select(0, idx).contiguous()          # row gather: data movement only
@@ -163,7 +165,7 @@ class RowsGatherFn(torch.autograd.Function):
         return dt, None
 
 
-class LSTMLayerFn(torch.autograd.Function):
+class LSTMLayerFn(ops.GradAwareFunction):
     """one layer of nn.LSTM(H, H) on a time-major sequence [T][H][B] (zero initial state)"""
 
     @staticmethod
@@ -174,7 +176,7 @@ class LSTMLayerFn(torch.autograd.Function):
         bias = (b_ih + b_hh).contiguous()
         xp = _gconv_raw(seq, w_ih.t().contiguous(), bias, 1, 1, 0, 4 * H, B, 1, 0, 4 * H, B)     # [T][4H][B]
         whhT = w_hh.t().contiguous()
-        need = any(ctx.needs_input_grad)
+        need = ops.wants_grad(ctx)
         hs = _f32(T + 1, H, B, device=dev)           # hs[t+1] = h_t, hs[0] = 0 (so hs[:T] is the h_{t-1} sequence)
         cs = _f32(T + 1, H, B, device=dev)
         hs[0].zero_(); cs[0].zero_()
@@ -189,6 +191,7 @@ class LSTMLayerFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         seq, hs, cs, gates, w_ih, w_hh = ctx.saved_tensors
+        ops._single_backward(ctx, "LSTMLayerFn")
         dout = dout.contiguous()
         T, H, B = seq.shape
         dev, st = seq.device, _stream()

@@ -49,6 +49,36 @@ def _f32(*shape, device):
     return torch.empty(shape, dtype=torch.float32, device=device)
 
 
+# ---------------------------------------------------------------------------------------------- grad mode
+# Inside Function.forward autograd has already switched grad mode off, and ctx.needs_input_grad only mirrors the
+# inputs' requires_grad flags -- under torch.no_grad() a module with trainable parameters still reports True there.
+# The forward-only fast paths (two-launch inference ResBlock, LSTM without saved activations) must key on "will a
+# backward ever run", i.e. on the grad mode of the CALLER: GradAwareFunction.apply records it before dispatch.
+_GRAD = {"on": True}
+
+
+class GradAwareFunction(torch.autograd.Function):
+    @classmethod
+    def apply(cls, *args, **kwargs):
+        _GRAD["on"] = torch.is_grad_enabled()
+        return super().apply(*args, **kwargs)
+
+
+def wants_grad(ctx) -> bool:
+    """True when the tape is recording AND some input asks for a gradient"""
+    return _GRAD["on"] and any(ctx.needs_input_grad)
+
+
+def _single_backward(ctx, what):
+    """the recurrences overwrite their saved gate activations with da in place (no second 4-5 GB buffer at B=256):
+    a second backward over a retained graph would read da as if it were activations -- refuse it loudly"""
+    if getattr(ctx, "_wm_consumed", False):
+        raise RuntimeError(f"{what}: backward was already run once on this graph; the saved gate activations were "
+                           "overwritten in place (retain_graph=True / per-loss backward calls are not supported -- "
+                           "sum the losses and call backward once, as py/main16.py:275-277 does)")
+    ctx._wm_consumed = True
+
+
 # ---------------------------------------------------------------------------------------------- side stream
 # Weight-gradient GEMMs do not feed the data path of backward.  When the parameters carry a pre-allocated gradient
 # destination (optim.FlatAdam sets p._wm_grad = view of the flat gradient bucket and enables this), they are
@@ -147,7 +177,7 @@ def pack_w64(w: torch.Tensor, kw: int, mode: int) -> torch.Tensor:
 
 
 # ------------------------------------------------------------------------------------------ ResBlock
-class ResBlockFn(torch.autograd.Function):
+class ResBlockFn(GradAwareFunction):
     """relu(x + BN2(conv2(relu(BN1(conv1(x))))))  -- ResBlock.forward, py/main16.py:124-125."""
 
     @staticmethod
@@ -170,7 +200,7 @@ class ResBlockFn(torch.autograd.Function):
             lib.wm_bn_eval_scale_shift(_p(g1), _p(be1), _p(rm1), _p(rv1), BN_EPS, _p(sc1), _p(sh1), st)
             lib.wm_bn_eval_scale_shift(_p(g2), _p(be2), _p(rm2), _p(rv2), BN_EPS, _p(sc2), _p(sh2), st)
             _conv3(x, None, w1, 0, None, None, None, b1, None, None, None, y1, None, B, T, 0, 0)
-            if not any(ctx.needs_input_grad) and _CONV["bf16x6"] and _CONV["schedule"] == 2 and T % 128 == 0:
+            if not wants_grad(ctx) and _CONV["bf16x6"] and _CONV["schedule"] == 2 and T % 128 == 0:
                 # inference: BN2 + residual add + ReLU ride in conv2's epilogue -- the block is two launches
                 _conv3(y1, None, w2, 0, sc1, sh1, None, b2, x, sc2, sh2, out, None, B, T, 1, 4)
                 return out
@@ -326,7 +356,7 @@ _LSTM_FUSED = _os.environ.get("WM_LSTM_FUSED", "1") == "1"     # 0: separate wm_
 _LSTM_BWD_FUSED = _os.environ.get("WM_LSTM_BWD_FUSED", "0") == "1"   # 1: wm_lstm_bwd + wm_lstm_dx as one launch
 
 
-class LSTMFn(torch.autograd.Function):
+class LSTMFn(GradAwareFunction):
     """nn.LSTM(64,64,batch_first=True) on channel-first frames: (B,64,T) -> (B,64,T); the two permutes of
     py/main16.py:152,154 are folded into the kernels' addressing."""
 
@@ -335,7 +365,7 @@ class LSTMFn(torch.autograd.Function):
         x = _frames(x, "LSTM input", 64)
         B, _, T = x.shape
         dev, st = x.device, _stream()
-        need_grad = any(ctx.needs_input_grad)
+        need_grad = wants_grad(ctx)
         h = torch.empty_like(x)
         if _LSTM_FUSED and T >= 8:                 # input projection inside the recurrence kernel (no xp tensor)
             gates = cst = None
@@ -360,6 +390,7 @@ class LSTMFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dh):
         x, h, gates, cst, w_ih, w_hh = ctx.saved_tensors
+        _single_backward(ctx, "LSTMFn")
         dh = dh.contiguous()
         B, _, T = x.shape
         dev, st = x.device, _stream()
@@ -386,6 +417,16 @@ class LSTMFn(torch.autograd.Function):
 
 
 # ------------------------------------------------------------------------------------------ embedding + convT
+# The reference's nn.Embedding raises IndexError for an out-of-range message id.  Mirroring that costs one 4-byte
+# device->host read per Generator call; set_index_check(False) (or WM_CHECK_INDEX=0) drops the sync for benchmark /
+# hipGraph loops whose messages are known to be in range (out-of-range ids then read as a zero row).
+_CHECK_INDEX = {"on": _os.environ.get("WM_CHECK_INDEX", "1") == "1"}
+
+
+def set_index_check(on: bool):
+    _CHECK_INDEX["on"] = bool(on)
+
+
 class EmbedFn(torch.autograd.Function):
     """nn.Embedding lookup, py/main16.py:158 (dense gradient like the reference's sparse=False table)."""
 
@@ -395,7 +436,10 @@ class EmbedFn(torch.autograd.Function):
         message = _chk(message, "message", 1, torch.int64)
         B = message.shape[0]
         vec = _f32(B, 64, device=table.device)
-        lib.wm_embed_gather(_p(table), _p(message), _p(vec), B, table.shape[0], None, _stream())
+        err = torch.zeros(1, dtype=torch.int32, device=table.device)
+        lib.wm_embed_gather(_p(table), _p(message), _p(vec), B, table.shape[0], _p(err), _stream())
+        if _CHECK_INDEX["on"] and int(err.item()) != 0:        # nn.Embedding raises IndexError (py/main16.py:158)
+            raise IndexError(f"message id out of range for an embedding table of {table.shape[0]} rows")
         ctx.save_for_backward(message)
         ctx.nrows = table.shape[0]
         return vec

@@ -67,9 +67,10 @@ class LaunchTimer:
         return sum(c for _, _, c in self.events) / len(self.events)
 
 
-def cpu_baseline(sample_batch=8, steps=2):
+def cpu_baseline(sample_batch=4, steps=1):
     """The oracle (CPU restatement, kind "port") timed on this box's host cores on a bounded sample of the same
-    workload: B=8 train steps (fwd + bwd + Adam), 1 warm-up + `steps` timed."""
+    workload: B=4 train steps (fwd + bwd + Adam), 1 warm-up + `steps` timed (about 20 s of CPU work in all, so the
+    default run stays a GPU run on the driver's clock)."""
     from oracle import recipes as R
     from oracle import wm_oracle as O
     nthreads = torch.get_num_threads()
@@ -118,9 +119,18 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # bare `python bench.py --gpus N`: start the N rank processes ourselves.  Nothing in THIS process has touched
+        # the GPU yet (import torch does not), and the ranks are children -- never a re-exec of a GPU process.
+        import socket
+        import subprocess
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.run(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")).returncode)
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     import torch.distributed as dist
     # rehearsal knobs (not used by the driver): WM_BENCH_SHARE_GPU=1 lets several ranks share one card and
@@ -158,7 +168,14 @@ def main():
         sync = (lambda: wmd.allreduce_gradients(list(G.parameters()) + list(D.parameters()))) if world > 1 else None
     else:
         opt = awm_amd.FlatAdam([G, D], lr=1e-3)
-        sync = (lambda: wmd.allreduce_flat_gradient(opt.grad)) if world > 1 else None
+        # Detector span all-reduced from post-accumulate hooks while the Generator's backward is still running, the rest
+        # when backward returns (distributed.GradSync).  WM_FORCE_SYNC=1 runs the same code on a one-rank communicator.
+        force = os.environ.get("WM_FORCE_SYNC") == "1"
+        if force and world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+            dist.init_process_group(os.environ.get("WM_DIST_BACKEND", "nccl"), rank=0, world_size=1)
+        gsync = wmd.GradSync(opt, early_modules=[D], force=force)
+        sync = gsync if (world > 1 or force) else None
     s, msg = synthetic_batch(args.batch, rank, dev)
 
     # dominant kernel: the 64->64 k3 forward convolution of the ResBlocks (epi = bias): wm_conv64_bf (bf16x6 split build,
@@ -266,7 +283,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline and args.model == "main16" and args.mode == "train":
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -13,7 +13,12 @@
  *   - activations are channel-first frames [B,64,T] exactly as the reference holds them, T % 4 == 0;
  *   - inputs are borrowed and never written; outputs / scratch are caller-allocated;
  *   - `stream` is a hipStream_t (pass torch.cuda.current_stream().cuda_stream); launchers enqueue and return,
- *     they never synchronise, allocate or free (graph-capture safe), and keep no mutable global state;
+ *     they never synchronise, allocate or free (graph-capture safe).  State kept across calls: (a) a per-device
+ *     cache of "dynamic-LDS opt-in done" bits (hipFuncSetAttribute is per device; idempotent, so launchers are
+ *     safe from several host threads and for one process driving several GPUs); (b) the two PROCESS-WIDE
+ *     experiment knobs wm_set_conv_bf_schedule / wm_set_lstm_dx_bf16x6 below -- they select between kernel
+ *     generations of equal results, are meant to be set once at start-up (or never: the defaults are the fast
+ *     builds) and are not synchronised with launches issued concurrently from other threads;
  *   - return value: 0 on success, else a hipError_t value (1 = invalid argument / unsupported variant).
  */
 #ifndef WM_HIP_H
@@ -158,7 +163,8 @@ int wm_bce_bwd(const float* logits, const long long* message, const float* g_loc
                int R, int T, int NO, wm_stream_t stream);
 int wm_l1_fwd(const float* x, float* partial, float* out, long long n, wm_stream_t stream);
 int wm_l1_bwd(const float* x, const float* g, float* dx, long long n, wm_stream_t stream);
-int wm_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,
+/* step >= 1 is the 1-based update count; bias corrections are formed in double (torch.optim.Adam semantics) */
+int wm_adam_step(float* p, const float* g, float* m, float* v, long long n, double lr, double beta1, double beta2, double eps,
                  int step, wm_stream_t stream);
 
 /* ---- main14b_2 deep-residual variant (py/main14b_2.py:83-224, BASELINE config 5): generic-shape convolutions -------

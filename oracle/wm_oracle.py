@@ -294,6 +294,74 @@ def step_losses(gsd: State, dsd: State, s: Tensor, message: Tensor, *, training:
 
 
 # ----------------------------------------------------------------------------
+# callers of the hot path: evaluation reductions and file-level wrappers
+# ----------------------------------------------------------------------------
+def evaluate_batch(gsd: State, dsd: State, s: Tensor, message: Tensor) -> "OrderedDict[str, Tensor]":
+    """per-batch quantities of evaluate_model, py/main16.py:383-403 (eval mode, no grad): per-clip mean detection
+    probability of the watermarked / clean halves, majority-vote bit accuracy, delta RMS."""
+    B = s.shape[0]
+    with torch.no_grad():
+        delta = postprocess(generator_forward(gsd, s, message, training=False))
+        logits = detector_forward(dsd, torch.cat([s + delta, s], dim=0), training=False)
+        avg_probs = torch.sigmoid(logits[:, :, 0]).mean(dim=1)
+        decoded_bits = (torch.sigmoid(logits[:B, :, 1:]) > 0.5).float().mean(dim=1) > 0.5
+        acc = (decoded_bits == message_bits_target(message, logits.shape[-1] - 1)).float().mean(dim=1)
+        rms = torch.sqrt((delta ** 2).mean(dim=[1, 2]))
+    return OrderedDict(delta=delta, logits=logits, prob_watermarked=avg_probs[:B], prob_clean=avg_probs[B:],
+                       bit_accuracy=acc, delta_rms=rms)
+
+
+def compute_si_snr(s: Tensor, s_hat: Tensor, eps: float = 1e-8) -> float:
+    """py/main16.py:764-773, reductions over dim=1 whatever the rank of the input.  Called on (1,N) waveforms it is the
+    usual SI-SNR; evaluate_unseen_file (:1294) calls it on (1,1,T) segments, where dim=1 is the size-1 channel axis:
+    s - mean == 0, so every segment yields 10*log10(0 / eps) = -inf.  Restated as is."""
+    s = s - s.mean(dim=1, keepdim=True)
+    s_hat = s_hat - s_hat.mean(dim=1, keepdim=True)
+    dot = torch.sum(s * s_hat, dim=1, keepdim=True)
+    alpha = dot / (torch.sum(s ** 2, dim=1, keepdim=True) + eps)
+    s_target = alpha * s
+    e_noise = s_hat - s_target
+    return (10 * torch.log10(torch.sum(s_target ** 2, dim=1) / (torch.sum(e_noise ** 2, dim=1) + eps))).mean().item()
+
+
+def _one_second_segments(waveform: Tensor, seg_len: int = AUDIO_LEN):
+    """`for i in range(0, N, AUDIO_LEN)` with the zero-padded tail, py/main16.py:1282-1285 / :1588-1591"""
+    for i in range(0, waveform.shape[1], seg_len):
+        seg = waveform[:, i:i + seg_len]
+        if seg.shape[1] < seg_len:
+            seg = F.pad(seg, (0, seg_len - seg.shape[1]))
+        yield seg.unsqueeze(0)
+
+
+def evaluate_unseen_waveform(gsd: State, dsd: State, waveform: Tensor, messages: Tensor):
+    """evaluate_unseen_file, py/main16.py:1263-1299, after its torchaudio load (the (1,N) mono 16 kHz waveform is the
+    input here); `messages[k]` replaces the per-segment torch.randint draw of :1287.  B = 1 per segment, like the
+    reference.  Returns (mean clean prob, mean watermarked prob, mean SI-SNR, mean delta RMS)."""
+    clean_probs, wm_probs, si, rms = [], [], [], []
+    with torch.no_grad():
+        for k, seg in enumerate(_one_second_segments(waveform)):
+            delta = generator_forward(gsd, seg, messages[k:k + 1], training=False)
+            seg_w = seg + delta
+            clean_probs.append(torch.sigmoid(detector_forward(dsd, seg, training=False)[:, :, 0]).mean().item())
+            wm_probs.append(torch.sigmoid(detector_forward(dsd, seg_w, training=False)[:, :, 0]).mean().item())
+            rms.append(torch.sqrt((delta ** 2).mean()).item())
+            si.append(compute_si_snr(seg, seg_w))
+    import numpy as np
+    return np.mean(clean_probs), np.mean(wm_probs), np.mean(si), np.mean(rms)
+
+
+def detect_prob_waveform(dsd: State, waveform: Tensor) -> float:
+    """detect_prob, py/main16.py:1575-1596, after its torchaudio load: mean over segments of each segment's mean
+    detection probability -- the zero-padded tail of the last segment counts (unlike detect_watermark, :1160-1164)."""
+    probs = []
+    with torch.no_grad():
+        for seg in _one_second_segments(waveform):
+            probs.append(torch.sigmoid(detector_forward(dsd, seg, training=False)[:, :, 0]).mean().item())
+    import numpy as np
+    return float(np.mean(probs))
+
+
+# ----------------------------------------------------------------------------
 # synthetic inputs (SURVEY.md 8(d)) -- shared by tests, smoke and bench
 # ----------------------------------------------------------------------------
 def synthetic_clips(batch: int, seed: int = 1234, T: int = AUDIO_LEN) -> Tensor:

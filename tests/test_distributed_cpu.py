@@ -73,6 +73,60 @@ def test_two_rank_allreduce_matches_big_batch(tmp_path):
     assert err < 5e-4, f"DP-averaged gradient differs from the big-batch gradient: {err:.2e}"
 
 
+class _FlatStore:
+    """CPU double of optim.FlatAdam's layout (params / grads as views of one flat buffer) for the GradSync test"""
+
+    def __init__(self, modules):
+        self.params = [p for m in modules for p in m.parameters()]
+        n = sum(p.numel() for p in self.params)
+        self.flat, self.grad, self._spans, off = torch.empty(n), torch.zeros(n), [], 0
+        for p in self.params:
+            k = p.numel()
+            self.flat[off:off + k].copy_(p.data.reshape(-1))
+            p.data = self.flat[off:off + k].view_as(p)
+            p.grad = self.grad[off:off + k].view_as(p)
+            self._spans.append((off, k)); off += k
+
+
+def _gradsync_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    from awm_amd import distributed as wmd
+    torch.manual_seed(3)
+    gen, det = torch.nn.Linear(6, 5), torch.nn.Sequential(torch.nn.Linear(5, 4), torch.nn.Linear(4, 1))
+    store = _FlatStore([gen, det])
+    sync = wmd.GradSync(store, early_modules=[det])
+    assert sync.early == (store._spans[2][0], 5 * 4 + 4 + 4 + 1)
+    x = torch.randn(8, 6, generator=torch.Generator().manual_seed(11))
+    lo, hi = wmd.shard_range(8, rank, world)
+    for _ in range(2):                                   # two rounds: the hook countdown must re-arm
+        store.grad.zero_()
+        det(gen(x[lo:hi])).mean().backward()
+        assert sync._work is not None, "the early (Detector) span was not launched from the accumulate hooks"
+        sync()
+    if rank == 0:
+        torch.save(store.grad.clone(), out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_gradsync_early_bucket_two_ranks(tmp_path):
+    """GradSync: Detector span all-reduced from the post-accumulate hooks while backward is still running, the rest after
+    backward; the result equals the big-batch gradient (equal shards, mean loss)"""
+    out = str(tmp_path / "g.pt")
+    mp.spawn(_gradsync_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = torch.load(out)
+    torch.manual_seed(3)
+    gen, det = torch.nn.Linear(6, 5), torch.nn.Sequential(torch.nn.Linear(5, 4), torch.nn.Linear(4, 1))
+    x = torch.randn(8, 6, generator=torch.Generator().manual_seed(11))
+    det(gen(x)).mean().backward()
+    want = torch.cat([p.grad.reshape(-1) for m in (gen, det) for p in m.parameters()])
+    assert float((got - want).abs().max()) < 1e-6
+
+
 def test_shard_range_covers_everything():
     from awm_amd import distributed as wmd
     for n in (1, 7, 256, 1000):

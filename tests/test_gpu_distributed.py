@@ -1,0 +1,97 @@
+"""Multi-GPU rehearsal on ONE GPU: two fresh child processes run the real HIP modules + FlatAdam + GradSync as
+world_size-2 ranks sharing the card over gloo (tests/dist_rehearsal.py), and bench.py's own N>1 launch path is driven
+the same way.  What cannot be covered here is RCCL over xGMI itself (needs >= 2 GPUs; the driver's scaling run)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from oracle import recipes as R
+from oracle import wm_oracle as O
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _spawn_ranks(script_args, world, extra_env=None, timeout=600):
+    """start `world` rank processes (children of this pytest process; nothing is re-exec'ed) and wait for all"""
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", **(extra_env or {}))
+        procs.append(subprocess.Popen([sys.executable] + script_args, env=env, cwd=ROOT, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(o)
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, f"rank {r} failed:\n{o[-3000:]}"
+    return outs
+
+
+@pytest.mark.timeout(900)
+def test_two_ranks_share_one_gpu_hip_path(tmp_path):
+    import awm_amd
+    dev = torch.device("cuda:0")
+    n_total, T = 4, 2048
+    _spawn_ranks([os.path.join(ROOT, "tests", "dist_rehearsal.py"), str(tmp_path), str(n_total), str(T)], world=2)
+    r0, r1 = torch.load(tmp_path / "rank0.pt"), torch.load(tmp_path / "rank1.pt")
+    # (ii) replicas identical after two exchanged steps (bit-exact: same averaged gradient, same Adam arithmetic)
+    assert torch.equal(r0["flat"], r1["flat"]), float((r0["flat"] - r1["flat"]).abs().max())
+    assert all(abs(a) < 1e6 for a in r0["losses"] + r1["losses"])
+    # (iii) rank-averaged flat gradient == single-process gradient of the concatenated batch (eval-mode BatchNorm)
+    gsd, dsd = R.reference_layout_init()
+    R.perturb_bn_(gsd, R.BN_SEED_G); R.perturb_bn_(dsd, R.BN_SEED_D)
+    G, D = awm_amd.Generator(16), awm_amd.Detector(16)
+    G.load_state_dict(gsd); D.load_state_dict(dsd)
+    G.to(dev).eval(); D.to(dev).eval()
+    opt = awm_amd.FlatAdam([G, D], lr=1e-3)
+    opt.zero_grad()
+    s = O.synthetic_clips(n_total, seed=41, T=T).to(dev)
+    msg = O.synthetic_messages(n_total, seed=42).to(dev)
+    total, _ = awm_amd.forward_losses(G, D, s, msg)
+    total.backward()
+    opt.finish_backward()
+    big = opt.grad.cpu()
+    avg = torch.load(tmp_path / "avg_grad.pt")
+    # per-parameter: fp32 summation order differs between one 4-clip batch and two 2-clip shards
+    for (off, k), p in zip(opt._spans, opt.params):
+        a, b = avg[off:off + k], big[off:off + k]
+        scale = float(b.abs().max())
+        if scale == 0.0:
+            assert float(a.abs().max()) == 0.0
+            continue
+        assert float((a - b).abs().max()) <= 2e-3 * scale + 1e-7, (off, k, float((a - b).abs().max()), scale)
+
+
+@pytest.mark.timeout(900)
+def test_bench_launches_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` (no torchrun in front, as the driver's bare form) starts two ranks itself; both share
+    the one GPU over gloo here.  One JSON line, n_gpus = 2, weak scaling: global batch = 2 x per-GPU batch."""
+    env = dict(os.environ, WM_BENCH_SHARE_GPU="1", WM_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("RANK", None); env.pop("WORLD_SIZE", None); env.pop("LOCAL_RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--batch", "8", "--no-cpu-baseline"], env=env, cwd=ROOT, capture_output=True, text=True, timeout=800)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["config"]["global_batch"] == 16
+    assert line["value"] > 0 and line["loss"] == line["loss"]

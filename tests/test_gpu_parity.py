@@ -21,6 +21,7 @@ pytestmark = pytest.mark.gpu
 
 FWD_TOL = 1e-4
 GRAD_TOL = 2e-3
+GRAD_FLOOR = 3e-4     # whole-network gradients vs an fp64 run: floor of the "<= 2 x CPU-fp32 distance" bar
 
 
 @pytest.fixture(scope="module")
@@ -47,6 +48,18 @@ def check(a, ref, tol, what=""):
     e = rel_err(a, ref)
     assert e <= tol, f"{what}: rel err {e:.3e} > {tol}"
     return e
+
+
+def check_elementwise(a, ref, what="", rtol=1e-4, atol_of_max=1e-6):
+    """north_star's 1e-4 rtol, element by element: |a - ref| <= rtol*|ref| + atol_of_max*max|ref|  (the absolute term is
+    the fp32 round-off floor of a value formed by summing terms of magnitude max|ref|)"""
+    assert a.shape == ref.shape, f"{what}: shape {tuple(a.shape)} vs {tuple(ref.shape)}"
+    a, ref = a.detach().double().cpu(), ref.detach().double().cpu()
+    bound = rtol * ref.abs() + atol_of_max * float(ref.abs().max())
+    excess = (a - ref).abs() - bound
+    worst = float(excess.max())
+    assert worst <= 0.0, (f"{what}: {int((excess > 0).sum())} of {a.numel()} elements outside rtol {rtol} + {atol_of_max}*max; "
+                          f"worst excess {worst:.3e} at ref = {float(ref.flatten()[int(excess.argmax())]):.3e}")
 
 
 def rnd(*shape, seed=0, scale=1.0):
@@ -137,13 +150,82 @@ def test_resblock_inference_fused_epilogue(awm, dev, B, T):
     m = awm.ResBlock(64)
     m.load_state_dict(sd)
     m.to(dev).eval()
-    with torch.no_grad():
-        y_fused = m(x.to(dev))
-    y_unfused = m(x.to(dev).requires_grad_())          # an input gradient is wanted -> the unfused path runs
+    assert all(p.requires_grad for p in m.parameters())      # default-constructed module: the parameters are trainable
+    calls = []
+    orig = awm.lib.wm_conv64_bf
+
+    def spy(*a):
+        calls.append(a[15])                                   # epi argument
+        return orig(*a)
+    awm.lib.wm_conv64_bf = spy
+    try:
+        with torch.no_grad():
+            y_fused = m(x.to(dev))
+        fused_calls = list(calls)
+        del calls[:]
+        y_unfused = m(x.to(dev).requires_grad_())          # grad mode on + an input gradient wanted -> the unfused path
+        unfused_calls = list(calls)
+    finally:
+        awm.lib.wm_conv64_bf = orig
+    if awm.ops.conv_bf16x6():
+        # under no_grad the block IS two launches, the second with BN2 + residual + ReLU in its epilogue (epi 4), although
+        # ctx.needs_input_grad reports the trainable parameters; with the tape recording, epi 4 is never used
+        assert fused_calls == [0, 4], fused_calls
+        assert unfused_calls == [0, 0], unfused_calls
     if awm.ops.conv_bf16x6():
         assert torch.equal(y_fused, y_unfused.detach()), float((y_fused - y_unfused.detach()).abs().max())
     yr = O.resblock({k: v.clone() for k, v in sd.items()}, "", x, False, {})
     check(y_fused, yr, FWD_TOL, "fused eval resblock")
+    check_elementwise(y_fused, yr, "fused eval resblock (element-wise)")
+
+
+def test_no_grad_lstm_skips_saved_activations(awm, dev):
+    """under torch.no_grad() the LSTM must take the forward-only launch (no [B,T,256] gates / [B,T,64] cell-state
+    tensors: 5 GB at B=256) although its weights require grad"""
+    G = awm.Generator(16).to(dev).eval()
+    seen = []
+    orig = awm.lib.wm_lstm_fwd_fused
+
+    def spy(*a):
+        seen.append((a[6], a[7]))                             # gates, cst pointers
+        return orig(*a)
+    awm.lib.wm_lstm_fwd_fused = spy
+    try:
+        s = O.synthetic_clips(1, seed=3, T=1024).to(dev)
+        with torch.no_grad():
+            G(s, torch.tensor([5], device=dev))
+        assert seen == [(None, None)], seen
+        del seen[:]
+        G(s, torch.tensor([5], device=dev))
+        assert seen[0][0] is not None and seen[0][1] is not None
+    finally:
+        awm.lib.wm_lstm_fwd_fused = orig
+
+
+def test_lstm_second_backward_raises(awm, dev):
+    """the recurrence overwrites its saved gate activations with da: a second backward over a retained graph must raise
+    instead of returning wrong gradients"""
+    from awm_amd import ops
+    g = torch.Generator().manual_seed(30)
+    wi, wh = (torch.rand(256, 64, generator=g) - 0.5) * 0.2, (torch.rand(256, 64, generator=g) - 0.5) * 0.2
+    bi, bh = torch.zeros(256), torch.zeros(256)
+    xd, wid, whd, bid, bhd = (t.to(dev).requires_grad_() for t in (rnd(1, 64, 64, seed=31), wi, wh, bi, bh))
+    h = ops.LSTMFn.apply(xd, wid, whd, bid, bhd)
+    h.sum().backward(retain_graph=True)
+    with pytest.raises(RuntimeError, match="already run once"):
+        h.sum().backward()
+
+
+def test_out_of_range_message_raises(awm, dev):
+    """nn.Embedding raises IndexError for a message id outside the table (py/main16.py:158)"""
+    G = awm.Generator(16).to(dev).eval()
+    s = O.synthetic_clips(2, seed=3, T=256).to(dev)
+    with pytest.raises(IndexError):
+        with torch.no_grad():
+            G(s, torch.tensor([5, 65536], device=dev))
+    with pytest.raises(IndexError):
+        with torch.no_grad():
+            G(s, torch.tensor([-1, 5], device=dev))
 
 
 @pytest.mark.parametrize("training", [False, True])
@@ -354,13 +436,16 @@ def test_g1_eval_forward_golden(awm, dev, golden):
     with torch.no_grad():
         d = G(s.to(dev), msg.to(dev))
         check(d, torch.from_numpy(golden["g1_delta"]), FWD_TOL, "G1 delta vs reference fixture")
+        check_elementwise(d, torch.from_numpy(golden["g1_delta"]), "G1 delta (element-wise)")
         d0 = G(s.to(dev))
         check(d0[..., ::97], torch.from_numpy(golden["g1_delta_nomsg_sub"]), FWD_TOL, "G1 delta (message omitted)")
         dp = awm.postprocess(d)
         check(dp, torch.from_numpy(golden["g1_delta_post"]), FWD_TOL, "G1 delta_post")
+        check_elementwise(dp, torch.from_numpy(golden["g1_delta_post"]), "G1 delta_post (element-wise)")
         lg = D(torch.cat([s.to(dev) + dp, s.to(dev)], 0))
         assert lg.shape == (4, 16000, 17)
         check(lg[:, ::97, :], torch.from_numpy(golden["g1_logits_sub"]), FWD_TOL, "G1 logits")
+        check_elementwise(lg[:, ::97, :], torch.from_numpy(golden["g1_logits_sub"]), "G1 logits (element-wise)")
         chk = golden["g1_logits_chk"]
         assert abs(float(lg.double().sum()) - chk[0]) <= 1e-4 * chk[1]
 
@@ -389,8 +474,11 @@ def test_g2_train_step_golden(awm, dev, golden):
     total, out = awm.forward_losses(G, D, s.to(dev), msg.to(dev))
     total.backward()
     for k in ("l1", "mel", "loud", "loc", "bce", "hf", "total"):
-        check(out[k].reshape(1), torch.tensor([float(golden[f"g2_{k}"])]), FWD_TOL, f"G2 {k}")
+        check(out[k].reshape(1), torch.tensor([float(golden[f"g2_{k}"])]), FWD_TOL, f"G2 {k}")     # scalars: this IS rtol 1e-4
     check(out["delta_raw"][..., ::97], torch.from_numpy(golden["g2_delta_raw_sub"]), FWD_TOL, "G2 delta_raw")
+    check_elementwise(out["delta_raw"][..., ::97], torch.from_numpy(golden["g2_delta_raw_sub"]), "G2 delta_raw (element-wise)")
+    check_elementwise(out["delta"][..., ::97], torch.from_numpy(golden["g2_delta_sub"]), "G2 delta (element-wise)")
+    check_elementwise(out["logits"][:, ::97, :], torch.from_numpy(golden["g2_logits_sub"]), "G2 logits (element-wise)")
     check(out["delta"][..., ::97], torch.from_numpy(golden["g2_delta_sub"]), FWD_TOL, "G2 delta")
     check(out["logits"][:, ::97, :], torch.from_numpy(golden["g2_logits_sub"]), FWD_TOL, "G2 logits")
     gp, dp = dict(G.named_parameters()), dict(D.named_parameters())
@@ -464,11 +552,13 @@ def test_all_grads_vs_oracle(awm, dev):
                         scale = max(float(ref[k].grad.abs().max()), float(ref[kw].grad.abs().max()))
                         e = float((p.grad.double().cpu() - ref[k].grad).abs().max()) / scale
                     worst = max(worst, e)
-                    # whole-network bar: 5e-3.  Besides clamp_peak (handled by the seed search) the reference loss has two
-                    # more derivative discontinuities that fp32 round-off can flip between implementations: the sign of
-                    # log-mel differences in F.l1_loss (|la - lb| ~ 1e-6 where the watermark is tiny, times 1/(mel+1e-5)
-                    # up to 1e5) and ReLU masks.  Per-kernel gradient tests above hold 2e-3 / 1e-4.
-                    assert e <= max(5e-3, 8 * e_cpu), f"{name}.{k}: grad rel err {e:.3e}, CPU fp32 {e_cpu:.3e} (bf16x6={mode})"
+                    # Besides clamp_peak (handled by the seed search) the reference loss has two more derivative
+                    # discontinuities that fp32 round-off can flip between implementations: the sign of log-mel differences
+                    # in F.l1_loss and ReLU masks -- they move the CPU fp32 run by the same amount (e_cpu is the yardstick).
+                    # per-parameter bar: no further from the fp64 run than twice the CPU fp32 reference arithmetic is
+                    # (measured round 1, tests/diag_grads.py: 0.7 ... 1.2 x for all but the tiny ones), with a floor of
+                    # 3e-4 of max|grad| for parameters whose CPU distance is ~1e-6 (fp64 accumulators in ATen's reductions)
+                    assert e <= max(2.0 * e_cpu, GRAD_FLOOR), f"{name}.{k}: grad rel err {e:.3e}, CPU fp32 {e_cpu:.3e} (bf16x6={mode})"
             print("worst grad rel err vs fp64", worst, "bf16x6 =", mode)
     finally:
         ops.set_conv_bf16x6(prev)
@@ -612,7 +702,7 @@ def test_default_constructor_no_message_bits(awm, dev, training):
             truth = r64[k].grad
             e_hip = rel_err(prm.grad.double().cpu(), truth)
             e_cpu = rel_err(r32[k].grad.double(), truth)
-            assert e_hip <= max(5e-3, 8.0 * e_cpu), f"{name}.{k} grad (bits = 0): {e_hip:.2e} vs fp64 (CPU fp32: {e_cpu:.2e})"
+            assert e_hip <= max(2.0 * e_cpu, GRAD_FLOOR), f"{name}.{k} grad (bits = 0): {e_hip:.2e} vs fp64 (CPU fp32: {e_cpu:.2e})"
 
 
 def test_full_size_properties_b256(awm, dev):
@@ -693,3 +783,122 @@ def test_file_level_embed_detect_batched(awm, dev):
     assert det["predicted_message"] == (ref_ml > 0).int().tolist()
     ev = awm.evaluate_batches(G, D, [O.synthetic_clips(4, seed=98)], device=dev)
     assert set(ev) == {"watermarked_prob", "clean_prob", "bit_accuracy", "delta_rms"} and all(np.isfinite(v) for v in ev.values())
+
+
+# ------------------------------------------------------------------------------------------ N2: scheduler-driven fused Adam
+def test_flat_adam_onecycle_and_state_dict(awm, dev):
+    """optim.FlatAdam is a torch.optim.Optimizer: OneCycleLR (py/main14d.py:491-507; cycles lr AND beta1 through
+    param_groups) drives it like torch.optim.Adam, and its state_dict is torch.optim.Adam's layout in both directions."""
+    B, T = 2, 2048
+    s = O.synthetic_clips(B, seed=95, T=T).to(dev)
+    msg = O.synthetic_messages(B, seed=96).to(dev)
+
+    def sched(opt):
+        return torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=2e-3, total_steps=6, pct_start=0.3, div_factor=25.0,
+                                                   final_div_factor=1e3, anneal_strategy="cos")
+    G1, D1, gsd, dsd = make_models(awm, dev)
+    G1.train(); D1.train()
+    opt1 = torch.optim.Adam(list(G1.parameters()) + list(D1.parameters()), lr=2e-3 / 25.0)
+    sc1 = sched(opt1)
+    G2, D2, _, _ = make_models(awm, dev, gsd, dsd)
+    G2.train(); D2.train()
+    opt2 = awm.FlatAdam([G2, D2], lr=2e-3 / 25.0)
+    sc2 = sched(opt2)
+    assert isinstance(opt2, torch.optim.Optimizer) and len(opt2.param_groups) == 1
+    for it in range(3):
+        l1 = float(awm.train_step(G1, D1, opt1, s, msg)["total"]); sc1.step()
+        l2 = float(awm.train_step(G2, D2, opt2, s, msg)["total"]); sc2.step()
+        assert abs(l1 - l2) <= 2e-4 * abs(l1), (it, l1, l2)
+        assert opt1.param_groups[0]["lr"] == opt2.param_groups[0]["lr"] and opt1.param_groups[0]["betas"] == opt2.param_groups[0]["betas"]
+    assert opt2.param_groups[0]["lr"] != 2e-3 / 25.0                       # the schedule really moved the fused update's lr
+    sd1, sd2 = opt1.state_dict(), opt2.state_dict()
+    assert set(sd2) == {"state", "param_groups"} and set(sd2["state"][0]) == {"step", "exp_avg", "exp_avg_sq"}
+    assert sd2["param_groups"][0]["params"] == sd1["param_groups"][0]["params"]
+    assert float(sd2["state"][0]["step"]) == float(sd1["state"][0]["step"]) == 3.0
+    # moments agree where the gradient is not round-off (exp_avg of the Detector head, a large well-conditioned gradient)
+    i_head = len(list(G1.parameters())) + [k for k, _ in D1.named_parameters()].index("model.3.weight")
+    check(sd2["state"][i_head]["exp_avg"], sd1["state"][i_head]["exp_avg"], 1e-3, "Adam exp_avg (Detector head)")
+    # interchange: torch.optim.Adam's state loads into a FlatAdam, and FlatAdam's into a torch.optim.Adam
+    G3, D3, _, _ = make_models(awm, dev, gsd, dsd)
+    opt3 = awm.FlatAdam([G3, D3], lr=1e-3)
+    opt3.load_state_dict(sd1)
+    assert opt3.t == 3 and opt3.param_groups[0]["lr"] == opt1.param_groups[0]["lr"]
+    off, k = opt3._spans[i_head]
+    assert torch.equal(opt3.m[off:off + k].view_as(sd1["state"][i_head]["exp_avg"]), sd1["state"][i_head]["exp_avg"].to(dev))
+    G4, D4, _, _ = make_models(awm, dev, gsd, dsd)
+    opt4 = torch.optim.Adam(list(G4.parameters()) + list(D4.parameters()), lr=1e-3)
+    opt4.load_state_dict(sd2)
+    assert float(opt4.state_dict()["state"][i_head]["step"]) == 3.0
+    # resumable checkpoint of py/main14d.py:540-558 through checkpoint.py, FlatAdam on both sides
+    import tempfile
+    from awm_amd import checkpoint
+    with tempfile.TemporaryDirectory() as td:
+        pth = os.path.join(td, "ckpt_latest.pth")
+        checkpoint.save_resumable(pth, 1, 3, 0.25, G2, D2, opt2, sc2)
+        G5, D5, _, _ = make_models(awm, dev, gsd, dsd)
+        opt5 = awm.FlatAdam([G5, D5], lr=2e-3 / 25.0)
+        sc5 = sched(opt5)
+        assert checkpoint.load_resumable(pth, G5, D5, opt5, sc5) == (1, 3, 0.25)
+        assert opt5.t == 3 and torch.equal(opt5.m, opt2.m) and torch.equal(opt5.v, opt2.v) and torch.equal(opt5.flat, opt2.flat)
+        assert sc5.state_dict()["last_epoch"] == sc2.state_dict()["last_epoch"]
+        l5 = float(awm.train_step(G5, D5, opt5, s, msg)["total"])
+        l2 = float(awm.train_step(G2, D2, opt2, s, msg)["total"])
+        assert l5 == l2                                          # resumed replica continues bit-identically
+
+
+# ------------------------------------------------------------------------------------------ N1 / N3: callers of the hot path
+def test_eval_forward_vs_oracle_and_reference_fixture(awm, dev):
+    """step.eval_forward / inference.evaluate_batches (evaluate_model, py/main16.py:369-423) against the oracle's
+    evaluate_batch and against the numbers the reference's own evaluate_model produced (G7 fixture): per-clip mean
+    sigmoid, majority-vote bit accuracy, delta RMS, pooled over a ragged pair of batches."""
+    ge = np.load(os.path.join(os.path.dirname(__file__), "golden", "main16_eval_golden.npz"))
+    G, D, gsd, dsd = make_models(awm, dev)
+    G.eval(); D.eval()
+    batches = [O.synthetic_clips(4, seed=501), O.synthetic_clips(2, seed=502)]
+    m_all = torch.from_numpy(ge["eval_messages"])
+    msgs = [m_all[:4], m_all[4:]]
+    for b, m in zip(batches, msgs):
+        out = awm.eval_forward(G, D, b.to(dev), m.to(dev))
+        ref = O.evaluate_batch(gsd, dsd, b, m)
+        for k in ("prob_watermarked", "prob_clean", "delta_rms"):
+            check(out[k], ref[k], FWD_TOL, f"eval_forward {k}")
+            check_elementwise(out[k], ref[k], f"eval_forward {k} (element-wise)")
+        assert torch.equal(out["bit_accuracy"].cpu(), ref["bit_accuracy"])
+    res = awm.evaluate_batches(G, D, batches, device=dev, messages=msgs)
+    for k in ("watermarked_prob", "clean_prob", "bit_accuracy", "delta_rms"):
+        assert abs(res[k] - float(ge[f"eval_{k}"])) <= 1e-4 * abs(float(ge[f"eval_{k}"])) + 1e-7, (k, res[k], float(ge[f"eval_{k}"]))
+
+
+def test_evaluate_unseen_file_and_detect_prob(awm, dev, tmp_path):
+    """N1: evaluate_unseen_file (py/main16.py:1263-1299) and detect_prob (:1575-1596) as one batched call each, against
+    the oracle's per-segment B=1 restatement: ragged tail segment, padded-tail mean-of-means, the reference's -inf SI-SNR
+    on (1,1,T) segments, the four-None return for an unreadable file, and a wav file path."""
+    G, D, gsd, dsd = make_models(awm, dev)
+    n = 2 * 16000 + 5000
+    w = O.synthetic_clips(1, seed=97, T=48000).reshape(1, -1)[:, :n]
+    msgs = torch.tensor([11, 22222, 65535])
+    got = awm.evaluate_unseen_file(w, G, D, device=dev, messages=msgs)
+    ref = O.evaluate_unseen_waveform(gsd, dsd, w, msgs)
+    assert len(got) == 4
+    for i, nm in ((0, "clean prob"), (1, "watermarked prob"), (3, "delta rms")):
+        assert abs(got[i] - float(ref[i])) <= 1e-4 * abs(float(ref[i])) + 1e-7, (nm, got[i], ref[i])
+    assert got[2] == float(ref[2]) == float("-inf")
+    assert awm.evaluate_unseen_file(str(tmp_path / "missing.wav"), G, D, device=dev) == (None, None, None, None)
+    p = awm.detect_prob(w, D, device=dev)
+    pr = O.detect_prob_waveform(dsd, w)
+    assert abs(p - pr) <= 1e-4 * pr + 1e-7, (p, pr)
+    # mean of per-segment means over the PADDED tail: not the mean of detect_waveform's trimmed temporal track
+    det = awm.detect_waveform(w, D, device=dev)
+    assert abs(p - det["mean_probability"]) > 1e-6
+    # shipped checkpoint + a real wav path (16-bit PCM): the file-level entry points end to end
+    ck = np.load(os.path.join(os.path.dirname(__file__), "golden", "detector_best_unprefixed.npz"))
+    D2 = awm.Detector(16)
+    D2.load_state_dict({k: torch.from_numpy(ck[k]) for k in ck.files})
+    D2.to(dev)
+    path = str(tmp_path / "clip.wav")
+    awm.save_audio(path, w)
+    wq = awm.load_audio(path)
+    pq = awm.detect_prob(path, D2, device=dev)
+    assert abs(pq - O.detect_prob_waveform({k: torch.from_numpy(ck[k]) for k in ck.files}, wq)) <= 1e-4 * pq + 1e-7
+    r4 = awm.evaluate_unseen_file(path, G, D2, device=dev)
+    assert all(isinstance(v, float) for v in r4) and 0.0 <= r4[0] <= 1.0 and 0.0 <= r4[1] <= 1.0
