@@ -9,7 +9,6 @@
 //   * Data gradients reuse the kernel with re-packed weights (dgrad of a strided conv = transposed conv and vice
 //     versa); the packing itself is pure data movement done by the host mirror.
 // Epilogue: + bias[channel] + vec[nb][channel] (message embedding) + residual, then optional ELU (alpha = 1).
-// This family is correctness-first (first build of config 5): 64x64 tiles, synchronous LDS staging, scalar loads.
 #include "wm_common.hpp"
 using namespace wm;
 
@@ -27,65 +26,280 @@ struct GConvArgs {
     int shp;             // padding of the transposed convolution (t' = n*st + phase - shp)
     int Cout, Lout;
     int act;             // 0 none, 1 ELU
+    int CI;              // input channels per LDS chunk (even; CI*K <= KR_MAX; CI*XW <= 256*XR)
+    int XW;              // input span of one N tile: (BN-1)*S + K
 };
 
-constexpr int GC = 8;    // input channels per LDS chunk
+constexpr int KR_MAX = 48;   // (channel, tap) rows of the weight image per chunk
+constexpr int XR = 16;       // input-tile elements a thread stages per chunk
 
-__global__ __launch_bounds__(256) void gconv_kernel(GConvArgs a) {
+// ELU (alpha = 1) with a cheap expm1: Taylor to the 6th order on (-0.35, 0] (error < 4e-7 of the value), exp(v) - 1 below
+__device__ __forceinline__ float elu1(float v) {
+    const float p = v * (1.f + v * (0.5f + v * (0.16666667f + v * (0.041666668f + v * (0.0083333338f + v * 0.0013888889f)))));
+    const float e = __expf(v) - 1.f;
+    const float n = v > -0.35f ? p : e;
+    return v > 0.f ? v : n;
+}
+
+// Implicit-GEMM tile kernel.  Workgroup = 4 waves as MW x (4/MW); a wave owns WM x WN blocks of 32 x 32 (fp32 MFMA
+// 32x32x2, the two k of an instruction = the two channels of a pair at one tap).  Per chunk of CI input channels the
+// workgroup stages the input rows [CI][XW] (dword loads, coalesced along time, any alignment) and the weight rows
+// [(pair, tap, parity)][BM] (float4 loads when Mtot % 4 == 0) through REGISTERS into the other LDS buffer while the
+// matrix cores work on the current one: one barrier per chunk.  Staging costs no address arithmetic inside the loop: every
+// element's 32-bit offset is formed once, the chunk advances two wave-uniform base pointers, LDS stores are unconditional
+// (the regions are padded to whole 256-thread passes) and zero padding is applied only by the tiles that touch a clip edge.
+template <int MW, int WM, int WN, bool VECW>
+__global__ __launch_bounds__(256) void gconv2_kernel(GConvArgs a) {
+    constexpr int NWN = 4 / MW, BM = MW * WM * 32, BN = NWN * WN * 32;
+    constexpr int WPT = VECW ? (KR_MAX * BM / 4 + 255) / 256 : (KR_MAX * BM + 255) / 256;   // weight pieces per thread
+    constexpr int WV = VECW ? 4 : 1;
     extern __shared__ __align__(16) float smem[];
-    const int XW = 63 * a.S + a.K;          // input span of a 64-position tile
-    const int KK = GC * a.K;                // (channel, tap) rows per chunk -- always even
-    float* Xs = smem;                       // [GC][XW]
-    float* Ws = Xs + GC * XW;               // [KK][64]
-    int* xoff = reinterpret_cast<int*>(Ws + KK * 64);   // [KK]: ci_local*XW + tap
+    const int K = a.K, S = a.S, CI = a.CI, XW = a.XW, KR = CI * K;
+    const int xsz = CI * XW;
+    const int nx = (xsz + 255) >> 8, xreg = nx * 256;                       // padded regions: whole passes of 256 threads
+    const int nwp = (KR * BM / WV + 255) >> 8, wreg = nwp * 256 * WV;
+    const int bufsz = xreg + wreg;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
-    const int wm_ = wave & 1, wn = wave >> 1;
-    const int n0 = blockIdx.x * 64, m0 = blockIdx.y * 64, nb = blockIdx.z;
-    const float* xb = a.x + (size_t)nb * a.Cin * a.Lin;
-    for (int i = tid; i < KK; i += 256) xoff[i] = (i / a.K) * XW + (i % a.K);
-    f32x16 acc;
+    const int wm_ = wave % MW, wn = wave / MW;
+    const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM, nb = blockIdx.z;
+    const int u0 = n0 * S - a.P;
+    const bool edge_tile = (u0 < 0) || (u0 + XW > a.Lin);                   // wave-uniform
+
+    // ---- chunk-invariant staging maps
+    unsigned xo[XR];            // ci * Lin + clamped column
+    unsigned xz = 0;            // bit i: element i is zero padding (outside the clip)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    const int u0 = n0 * a.S - a.P;
-    for (int c0 = 0; c0 < a.Cin; c0 += GC) {
-        __syncthreads();
-        for (int i = tid; i < GC * XW; i += 256) {
-            const int ci = i / XW, j = i - ci * XW, u = u0 + j, c = c0 + ci;
-            const bool ok = (c < a.Cin) && (u >= 0) && (u < a.Lin);
-            const float v = xb[(size_t)min(c, a.Cin - 1) * a.Lin + min(max(u, 0), a.Lin - 1)];   // branch-free load
-            Xs[i] = ok ? v : 0.f;
+    for (int i = 0; i < XR; ++i) {
+        const int idx = tid + 256 * i;
+        const int ci = min(idx / XW, CI - 1), j = idx - (idx / XW) * XW, u = u0 + j;
+        xz |= ((u < 0 || u >= a.Lin) ? 1u : 0u) << i;
+        xo[i] = (unsigned)(ci * a.Lin + min(max(u, 0), a.Lin - 1));
+    }
+    unsigned wo[WPT];           // row * Mtot + m0 + column of the chunk's weight slab (0 for pieces outside it)
+#pragma unroll
+    for (int i = 0; i < WPT; ++i) {
+        const int idx = tid + 256 * i;
+        int r, c;
+        if (VECW) { r = idx / (BM / 4); c = (idx - r * (BM / 4)) * 4; } else { r = idx / BM; c = idx - r * BM; }
+        const int pr = r >> 1, q = pr / K, tap = pr - q * K, ci = 2 * q + (r & 1);
+        const bool ok = (r < KR) && (m0 + c < a.Mtot);
+        wo[i] = ok ? (unsigned)((ci * K + tap) * a.Mtot + m0 + c) : 0u;
+    }
+
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    float xr[XR];
+    f32x4 wr4[VECW ? WPT : 1];
+    float wr1[VECW ? 1 : WPT];
+    const float* xb = a.x + (size_t)nb * a.Cin * a.Lin;      // advanced by CI rows per chunk (wave-uniform)
+    const float* wb = a.wp;                                  // advanced by CI*K rows per chunk
+
+    auto load_chunk = [&](int c0) {
+        const int crem = a.Cin - c0;
+        if (crem >= CI) {                                    // full chunk: offsets only
+#pragma unroll
+            for (int i = 0; i < XR; ++i)
+                if (i < nx) xr[i] = xb[xo[i]];
+#pragma unroll
+            for (int i = 0; i < WPT; ++i) {
+                if (i < nwp) {
+                    if (VECW) wr4[i] = *reinterpret_cast<const f32x4*>(wb + wo[i]);
+                    else wr1[i] = wb[wo[i]];
+                }
+            }
+        } else {                                             // last chunk of a channel count that CI does not divide
+#pragma unroll
+            for (int i = 0; i < XR; ++i) {
+                if (i < nx) {
+                    const int idx = tid + 256 * i;
+                    const int ci = min(idx / XW, CI - 1);
+                    const float v = xb[xo[i] - (unsigned)((ci - min(ci, crem - 1)) * a.Lin)];
+                    xr[i] = ci < crem ? v : 0.f;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < WPT; ++i) {
+                if (i < nwp) {
+                    const int idx = tid + 256 * i;
+                    const int r = VECW ? idx / (BM / 4) : idx / BM;
+                    const int ci = 2 * ((r >> 1) / K) + (r & 1);
+                    const bool ok = ci < crem;
+                    if (VECW) {
+                        const f32x4 v = *reinterpret_cast<const f32x4*>(wb + (ok ? wo[i] : 0u));
+                        wr4[i] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+                    } else {
+                        const float v = wb[ok ? wo[i] : 0u];
+                        wr1[i] = ok ? v : 0.f;
+                    }
+                }
+            }
         }
-        for (int i = tid; i < KK * 64; i += 256) {
-            const int kk = i >> 6, m = i & 63, gk = c0 * a.K + kk, gm = m0 + m;
-            const bool ok = (gk < a.Cin * a.K) && (gm < a.Mtot);
-            const float v = a.wp[(size_t)min(gk, a.Cin * a.K - 1) * a.Mtot + min(gm, a.Mtot - 1)];
-            Ws[i] = ok ? v : 0.f;
+        if (edge_tile) {
+#pragma unroll
+            for (int i = 0; i < XR; ++i)
+                if (i < nx) xr[i] = ((xz >> i) & 1u) ? 0.f : xr[i];
         }
+        xb += (size_t)CI * a.Lin;
+        wb += (size_t)KR * a.Mtot;
+    };
+    auto store_chunk = [&](float* buf) {
+#pragma unroll
+        for (int i = 0; i < XR; ++i)
+            if (i < nx) buf[tid + 256 * i] = xr[i];
+        float* Ws = buf + xreg;
+#pragma unroll
+        for (int i = 0; i < WPT; ++i) {
+            if (i < nwp) {
+                if (VECW) *reinterpret_cast<f32x4*>(Ws + (tid + 256 * i) * 4) = wr4[i];
+                else Ws[tid + 256 * i] = wr1[i];
+            }
+        }
+    };
+
+    const int nchunks = (a.Cin + CI - 1) / CI;
+    load_chunk(0);
+    store_chunk(smem);
+    __syncthreads();
+    const int npair = KR >> 1;
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const float* cur = smem + (ch & 1) * bufsz;
+        if (ch + 1 < nchunks) load_chunk((ch + 1) * CI);
+        const float* wa = cur + xreg + half * BM + wm_ * (WM * 32) + l31;
+        const float* xp = cur + half * XW + (wn * (WN * 32) + l31) * S;
+        // software-pipelined pair loop, two pairs per trip with two operand sets: each set is read one MFMA group (4 x 64
+        // cycles) before it is used, so no LDS latency is exposed
+        float av[WM], bv[WN], an[WM], bn[WN];
+        int tap = 0, xoff = 0;
+        auto advance = [&]() {
+            ++tap; ++xoff;
+            if (tap == K) { tap = 0; xoff += 2 * XW - K; }
+            wa += 2 * BM;
+        };
+        auto rd = [&](float (&A_)[WM], float (&B_)[WN]) {
+#pragma unroll
+            for (int i = 0; i < WM; ++i) A_[i] = wa[i * 32];
+#pragma unroll
+            for (int j = 0; j < WN; ++j) B_[j] = xp[xoff + j * 32 * S];
+        };
+        auto mm = [&](const float (&A_)[WM], const float (&B_)[WN]) {
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j) acc[i][j] = mfma32(A_[i], B_[j], acc[i][j]);
+        };
+        rd(av, bv);
+        // (reads past the last pair stay inside the workgroup's LDS allocation: see the slack in launch_gconv2)
+        for (int p = 0; p < npair; p += 2) {
+            advance();
+            rd(an, bn);
+            __builtin_amdgcn_sched_barrier(0);
+            mm(av, bv);
+            __builtin_amdgcn_sched_barrier(0);
+            advance();
+            rd(av, bv);
+            __builtin_amdgcn_sched_barrier(0);
+            if (p + 1 < npair) mm(an, bn);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (ch + 1 < nchunks) store_chunk(smem + ((ch + 1) & 1) * bufsz);
         __syncthreads();
-        const float* ap = Ws + wm_ * 32 + l31;
-        const float* bp = Xs + (wn * 32 + l31) * a.S;
-        for (int ks = 0; ks < KK / 2; ++ks) {
-            const int kk = 2 * ks + half;
-            acc = mfma32(ap[kk * 64], bp[xoff[kk]], acc);
+    }
+
+    // ---- epilogue: + bias + per-clip vector + residual, ELU, (pixel-shuffled) store
+    const unsigned obase = (unsigned)nb * (unsigned)a.Cout;               // output row index base (rows of Lout floats)
+    float* __restrict__ yb = a.y;
+    const float* __restrict__ rsb = a.res;
+    if (a.st == 1) {
+#pragma unroll
+        for (int i = 0; i < WM; ++i) {
+            const int mrow0 = m0 + (wm_ * WM + i) * 32 + 4 * half;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mrow0 + (r & 3) + 8 * (r >> 2);
+                if (m >= a.Mtot) continue;
+                float add = a.bias ? a.bias[m] : 0.f;
+                if (a.vec) add += a.vec[obase + m];
+                const size_t rowoff = (size_t)(obase + m) * a.Lout;
+#pragma unroll
+                for (int j = 0; j < WN; ++j) {
+                    const int n = n0 + (wn * WN + j) * 32 + l31;
+                    if (n < a.Nout) {
+                        float v = acc[i][j][r] + add;
+                        if (rsb) v += rsb[rowoff + n];
+                        if (a.act == 1) v = elu1(v);
+                        yb[rowoff + n] = v;
+                    }
+                }
+            }
+        }
+    } else {
+        const unsigned inv = (65536u + (unsigned)a.st - 1u) / (unsigned)a.st;   // exact m / st for m < 8192, st <= 8
+#pragma unroll
+        for (int i = 0; i < WM; ++i) {
+            const int mrow0 = m0 + (wm_ * WM + i) * 32 + 4 * half;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mrow0 + (r & 3) + 8 * (r >> 2);
+                if (m >= a.Mtot) continue;
+                const int co = (int)(((unsigned)m * inv) >> 16), ph = m - co * a.st;
+                float add = a.bias ? a.bias[co] : 0.f;
+                if (a.vec) add += a.vec[obase + co];
+                const size_t rowoff = (size_t)(obase + co) * a.Lout;
+#pragma unroll
+                for (int j = 0; j < WN; ++j) {
+                    const int n = n0 + (wn * WN + j) * 32 + l31;
+                    const int t = n * a.st + ph - a.shp;
+                    if (n < a.Nout && t >= 0 && t < a.Lout) {
+                        float v = acc[i][j][r] + add;
+                        if (rsb) v += rsb[rowoff + t];
+                        if (a.act == 1) v = elu1(v);
+                        yb[rowoff + t] = v;
+                    }
+                }
+            }
         }
     }
-    const int n = n0 + wn * 32 + l31;
-    if (n >= a.Nout) return;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm_ * 32 + mfma_row(r, half);
-        if (m >= a.Mtot) continue;
-        int co = m, t = n;
-        if (a.st > 1) { co = m / a.st; t = n * a.st + (m - co * a.st) - a.shp; }
-        if (t < 0 || t >= a.Lout) continue;
-        float v = acc[r];
-        if (a.bias) v += a.bias[co];
-        if (a.vec) v += a.vec[(size_t)nb * a.Cout + co];
-        const size_t o = ((size_t)nb * a.Cout + co) * a.Lout + t;
-        if (a.res) v += a.res[o];
-        if (a.act == 1) v = v > 0.f ? v : expm1f(v);
-        a.y[o] = v;
+}
+
+// largest even ci <= lim that divides Cin (so no partial tail chunk exists), unless that costs more than half the chunk
+static int pick_ci(int Cin, int lim) {
+    lim &= ~1;
+    if (lim >= Cin + (Cin & 1)) return Cin + (Cin & 1);
+    for (int c = lim; c >= 2 && 2 * c > lim; c -= 2)
+        if (Cin % c == 0) return c;
+    return lim;
+}
+
+template <int MW, int WM, int WN, bool VECW>
+int launch_gconv2(GConvArgs a, hipStream_t stream) {
+    constexpr int BM = MW * WM * 32, BN = (4 / MW) * WN * 32, WV = VECW ? 4 : 1;
+    a.XW = (BN - 1) * a.S + a.K;
+    int lim = KR_MAX / a.K;                                 // weight rows per chunk <= KR_MAX
+    const int cx = (256 * XR) / a.XW;                       // staged input elements per thread <= XR
+    if (cx < lim) lim = cx;
+    if (lim < 2) return (int)hipErrorInvalidValue;
+    a.CI = pick_ci(a.Cin, lim);
+    const int KR = a.CI * a.K;
+    const size_t xreg = (((size_t)a.CI * a.XW + 255) >> 8) * 256, wreg = (((size_t)KR * BM / WV + 255) >> 8) * 256 * WV;
+    // + slack: the pipelined pair loop reads up to two pairs past the chunk (four weight rows, two input rows further)
+    const size_t lds = (2 * (xreg + wreg) + 4 * BM + 4 * (size_t)a.XW + 64) * sizeof(float);
+    if (lds > 160 * 1024) return (int)hipErrorInvalidValue;
+    auto kern = gconv2_kernel<MW, WM, WN, VECW>;
+    static wm::DevOnce once;
+    if (!wm::dev_done(once)) {
+        WM_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        wm::dev_mark(once);
     }
+    dim3 grid((a.Nout + BN - 1) / BN, (a.Mtot + BM - 1) / BM, a.NB);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, a);
+    WM_CHECK_LAUNCH();
+    return 0;
 }
 
 // [A][C][L] -> [L][C][A]   (batch-major <-> time-major sequence layouts around the LSTM)
@@ -144,89 +358,387 @@ __global__ __launch_bounds__(64) void lstm_h_step_fwd_kernel(const float* xp, co
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Generic weight gradient:  G[a][b][k] += sum_{nb,t} A[nb][a][t] * Bx[nb][b][t*S + k - P]      (k < K <= 16)
-//   Conv1d:           A = dL/dy (rows = out channels),  Bx = layer input  -> dW[out][in][k]
-//   ConvTranspose1d:  A = layer input (rows = in channels), Bx = dL/dy    -> dW[in][out][k]   (S = stride, P = padding)
-//   Linear / LSTM:    K = 1.
-// One wave owns a 32x32 (a,b) tile for every tap (K accumulators); the workgroup's 4 waves split each 64-position
-// chunk; a workgroup walks a strided list of (nb, chunk) pairs and flushes once with float atomics (the slabs of the
-// largest layer would be 8 MB per workgroup, so the fixed-order slab reduce of the main16 kernels does not scale here;
-// consequence: the summation order over workgroups is not fixed, results are reproducible to fp32 round-off only).
-// dbias[a] += sum A[a][t] is produced by the b-tile-0 workgroups.
-template <int KMAX>
-__global__ __launch_bounds__(256) void gwgrad_kernel(const float* __restrict__ A, const float* __restrict__ Bx,
-                                                     float* __restrict__ G, float* __restrict__ dbias, int NB, int Ca, int Cb,
-                                                     int La, int Lb, int K, int S, int P, int TC) {
-    // Workgroup tile = 64 (a) x 64 (b); wave (ma, mb) owns one 32 x 32 block of it for every tap and walks the WHOLE
-    // chunk, so a staged element feeds two waves (the first version staged a 32 x 32 tile and split the chunk over the
-    // waves: twice the LDS traffic and four times the global traffic per MFMA).  TC = positions per LDS chunk (multiple of
-    // 64, chosen by the launcher so that two workgroups fit a CU: one stages while the other multiplies).
+// Generic weight gradient as ONE plain GEMM with the taps folded into the column index:
+//     G[a][j] = sum_{nb,t} A[nb][a][t] * Bx[nb][b][t + k - P],      j = b*K + k   (= the memory order of dW[a][b][k])
+//   Conv1d (stride 1): A = dL/dy (rows = out channels),  Bx = layer input  -> dW[out][in][k]
+//   Linear / LSTM:     K = 1 (the "time" axis is whatever axis is contiguous: positions or batch columns)
+//   strided Conv1d and ConvTranspose1d: the strided operand is first re-laid by wm_gather_taps (tap planes / stride
+//   phases become channels), which turns them into stride-1 problems with K = 1 / K = 2; `remap` puts the columns back
+//   into the weight's own order in the reduce.
+// M = Ca rows, N = Cb*K columns, contraction over (clip, position).  A wave owns a 32 x (32*NS) block (NS <= 4
+// accumulators, whatever K is: a 8 x 8 x 3 layer is ONE MFMA per position pair, not three); the workgroup's four waves
+// split rows (WA), columns (WJW) and -- when the matrix is smaller than that -- the positions of each chunk (WT, summed in
+// fixed order at the end).  Per chunk of TC positions the A rows and the Bx rows the tile's columns touch are staged
+// through registers (buffer loads: wave-uniform row offset + one per-lane constant, no vector-ALU address arithmetic)
+// into LDS while the matrix cores work on the previous chunk; lanes run along the position axis (coalesced), LDS pitches
+// are chosen so both operand reads are conflict-free (A: odd pitch, read down a column; Bx: pitch == K mod 32, so
+// column j of the tile reads bank j).
+// Split-K over gridDim.y: every workgroup writes its partial tile to slab[z] and a fixed-order reduce kernel forms the
+// result -- no float atomics, bit-reproducible.  dbias[a] = sum A[a][t] rides along (column tile 0, VALU sums of the
+// staged rows).
+struct GWArgs {
+    const float* A;
+    const float* Bx;
+    float* slab;     // [gz][Ca][NJ]
+    float* slabb;    // [gz][Ca] or null
+    int NB, Ca, Cb, La, Lb, K, P;
+    long long bcs;   // floats between consecutive clips of Bx (>= Cb*Lb: Bx may be a channel slice of a wider tensor)
+    int NJ;          // Cb*K
+    int TC;          // positions per chunk: multiple of 8
+    int nchunks;     // chunks per clip
+    int nsub;        // 32-column blocks per wave (1..4)
+    int WJW, WT;     // waves along the columns / along the positions of a chunk (WA*WJW*WT == 4)
+    int ntj;         // column tiles
+    int NBCH;        // Bx rows (channels) staged per workgroup
+    int ncb;         // 64-position blocks per staged row (A and Bx alike)
+    int AP, BP;      // LDS pitches
+    int nwork;       // NB * nchunks
+};
+
+constexpr int GW_RA = 16;   // A staging units per wave and chunk (unit = one wave-wide dword load)
+constexpr int GW_RB = 36;   // Bx staging units per wave and chunk
+
+typedef __amdgpu_buffer_rsrc_t wm_srd_t;   // 128-bit buffer resource descriptor (kept in scalar registers)
+
+// buffer descriptor over [p, p + bytes): 32-bit per-lane byte offsets + a scalar offset, reads past the end return 0
+__device__ __forceinline__ wm_srd_t make_srd(const float* p, size_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), (short)0, (int)(bytes > 0xfffff000ull ? 0xfffff000ull : bytes),
+                                             0x00020000);
+}
+__device__ __forceinline__ float buf_load(wm_srd_t srd, unsigned voff_bytes, unsigned soff_bytes) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd, (int)voff_bytes, (int)soff_bytes, 0));
+}
+
+template <int WA, int NS>
+__global__ __launch_bounds__(256) void gwgrad2_kernel(GWArgs g) {
+    constexpr int TA = 32 * WA;
     extern __shared__ __align__(16) float smem[];
-    const int BW = (TC - 1) * S + K;            // Bx span of a chunk
-    const int AS = TC + 1, BS = BW | 1;         // odd strides: operands are read down a column
-    float* As = smem;                           // [64][AS]
-    float* Bs = smem + 64 * AS;                 // [64][BS]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
-    const int ma = wave & 1, mb = wave >> 1;
-    const int a0 = blockIdx.x * 64, b0 = blockIdx.y * 64;
-    const int nchunks = (La + TC - 1) / TC, nwork = NB * nchunks;
-    f32x16 acc[KMAX];
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wa = wave % WA, rest = wave / WA, wj = rest % g.WJW, wt = rest / g.WJW;
+    const int ta = blockIdx.x / g.ntj, tj = blockIdx.x - ta * g.ntj;
+    const int TJ = g.WJW * 32 * g.nsub;
+    const int a0 = ta * TA, j0 = tj * TJ, b0 = j0 / g.K;
+    const int TC = g.TC, BW = TC + g.K - 1, ncb = g.ncb;
+    // staging geometry (wave-uniform).  A unit is one wave-wide dword load: 64 positions of one row, or (rows <= 32 wide)
+    // 32 positions of two rows.  Only rows that exist are staged; LDS rows are padded to whole units (no store predicate).
+    const int rpu = BW <= 32 ? 2 : 1;                       // rows per unit, A and Bx alike (BW >= TC)
+    const int a_rows = min(TA, g.Ca - a0), b_rows = min(g.NBCH, g.Cb - b0);
+    const int a_units = ((a_rows + rpu - 1) / rpu) * ncb, b_units = ((b_rows + rpu - 1) / rpu) * ncb;
+    const int row_l = rpu == 2 ? half : 0, col_l = rpu == 2 ? l31 : lane;
+    const int asz = TA * g.AP, zrow = asz + g.NBCH * g.BP;         // + one all-zero row: what columns past NJ read
+    const unsigned inv_ncb = (65536u + (unsigned)ncb - 1u) / (unsigned)ncb;
+    const unsigned vA = (unsigned)(row_l * g.La + col_l), vB = (unsigned)(row_l * g.Lb + col_l);
+    const unsigned lA = (unsigned)(row_l * g.AP + col_l), lB = (unsigned)(asz + row_l * g.BP + col_l);
+    const bool even_rows = ((a_rows % rpu) == 0) && ((b_rows % rpu) == 0);
+
+    // per-lane column maps of the MFMA B operand (LDS float index of position 0 of the column)
+    int boff[NS];
 #pragma unroll
-    for (int k = 0; k < KMAX; ++k)
+    for (int jt = 0; jt < NS; ++jt) {
+        const int j = j0 + (wj * g.nsub + jt) * 32 + l31;
+        const int b = j / g.K, k = j - b * g.K;
+        const bool ok = (jt < g.nsub) && (j < g.NJ);
+        boff[jt] = (ok ? asz + (b - b0) * g.BP + k : zrow) + half;
+    }
+    f32x16 acc[NS];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
+    for (int jt = 0; jt < NS; ++jt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[jt][r] = 0.f;
     float bsum = 0.f;
-    for (int w = blockIdx.z; w < nwork; w += gridDim.z) {
-        const int nb = w / nchunks, t0 = (w - nb * nchunks) * TC;
-        const float* Ab = A + (size_t)nb * Ca * La;
-        const float* Bb = Bx + (size_t)nb * Cb * Lb;
-        __syncthreads();
-        // staging: wave w copies rows w, w + 4, ...; lanes run along the position axis (coalesced, branch-free)
-        for (int r = wave; r < 64; r += 4) {
-            const int a = a0 + r;
-            const float* src = Ab + (size_t)min(a, Ca - 1) * La;
-            for (int j = lane; j < TC; j += 64) {
-                const int t = t0 + j;
-                const float v = src[min(t, La - 1)];
-                As[r * AS + j] = (a < Ca && t < La) ? v : 0.f;
-            }
-        }
-        const int u0 = t0 * S - P;
-        for (int r = wave; r < 64; r += 4) {
-            const int b = b0 + r;
-            const float* src = Bb + (size_t)min(b, Cb - 1) * Lb;
-            for (int j = lane; j < BW; j += 64) {
-                const int u = u0 + j;
-                const float v = src[min(max(u, 0), Lb - 1)];
-                Bs[r * BS + j] = (b < Cb && u >= 0 && u < Lb) ? v : 0.f;
-            }
-        }
-        __syncthreads();
-        const float* ap = As + (ma * 32 + l31) * AS + half;
-        const float* bp = Bs + (mb * 32 + l31) * BS + half * S;
-#pragma unroll 4
-        for (int s = 0; s < TC / 2; ++s) {
-            const float av = ap[2 * s];
+    const bool do_bias = (g.slabb != nullptr) && (tj == 0);
+    const int bparts = 256 / TA, brow = tid % TA, bpart = tid / TA, bcpp = TC / bparts;
+
+    float ra[GW_RA], rb[GW_RB];
+    auto load_work = [&](int w) {
+        int wv = wave;
+        asm volatile("" : "+s"(wv));                         // opaque: the per-unit scalars are not hoisted out of the chunk loop
+        const int nb = w / g.nchunks, t0 = (w - nb * g.nchunks) * TC, u0 = t0 - g.P;
+        const float* Ab = g.A + (size_t)nb * g.Ca * g.La;
+        const float* Bb = g.Bx + (size_t)nb * g.bcs;
+        // fast path: every lane of every unit reads inside its own row of the clip -- buffer loads with a wave-uniform
+        // offset (row, chunk start) plus one per-lane constant, no address arithmetic on the vector ALU (which the fp32
+        // matrix instructions share)
+        const bool fast = even_rows && (t0 + ncb * (rpu == 2 ? 32 : 64) <= g.La) && (u0 >= 0) && (u0 + ncb * (rpu == 2 ? 32 : 64) <= g.Lb);
+        if (fast) {
+            const wm_srd_t sa = make_srd(Ab, ((size_t)(g.NB - nb) * g.Ca * g.La) * sizeof(float));
+            const wm_srd_t sb = make_srd(Bb, ((size_t)(g.NB - 1 - nb) * g.bcs + (size_t)g.Cb * g.Lb) * sizeof(float));
 #pragma unroll
-            for (int k = 0; k < KMAX; ++k)
-                if (k < K) acc[k] = mfma32(av, bp[2 * s * S + k], acc[k]);
+            for (int i = 0; i < GW_RA; ++i) {
+                const int u = wv + 4 * i;
+                if (u < a_units) {
+                    const int rg = (int)(((unsigned)u * inv_ncb) >> 16), cb = u - rg * ncb;
+                    ra[i] = buf_load(sa, vA * 4u, (unsigned)((a0 + rg * rpu) * g.La + t0 + cb * 64) * 4u);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < GW_RB; ++i) {
+                const int u = wv + 4 * i;
+                if (u < b_units) {
+                    const int rg = (int)(((unsigned)u * inv_ncb) >> 16), cb = u - rg * ncb;
+                    rb[i] = buf_load(sb, vB * 4u, (unsigned)((b0 + rg * rpu) * g.Lb + u0 + cb * 64) * 4u);
+                }
+            }
+        } else {                                             // clip edges / odd row counts: clamp every address, zero the padding
+#pragma unroll
+            for (int i = 0; i < GW_RA; ++i) {
+                const int u = wv + 4 * i;
+                if (u < a_units) {
+                    const int rg = (int)(((unsigned)u * inv_ncb) >> 16), cb = u - rg * ncb;
+                    const int a = a0 + rg * rpu + row_l, col = cb * 64 + col_l, t = t0 + col;
+                    const bool ok = (a < g.Ca) && (col < TC) && (t < g.La);
+                    const float v = Ab[(unsigned)(min(a, g.Ca - 1) * g.La + min(t, g.La - 1))];
+                    ra[i] = ok ? v : 0.f;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < GW_RB; ++i) {
+                const int u = wv + 4 * i;
+                if (u < b_units) {
+                    const int rg = (int)(((unsigned)u * inv_ncb) >> 16), cb = u - rg * ncb;
+                    const int b = b0 + rg * rpu + row_l, col = cb * 64 + col_l, uu = u0 + col;
+                    const bool ok = (b < g.Cb) && (col < BW) && (uu >= 0) && (uu < g.Lb);
+                    const float v = Bb[(unsigned)(min(b, g.Cb - 1) * g.Lb + min(max(uu, 0), g.Lb - 1))];
+                    rb[i] = ok ? v : 0.f;
+                }
+            }
         }
-        if (dbias && blockIdx.y == 0) {          // row tid & 63, quarter tid >> 6 of the chunk
-            const float* rp = As + (tid & 63) * AS + (tid >> 6) * (TC / 4);
-            for (int j = 0; j < TC / 4; ++j) bsum += rp[j];
+    };
+    auto store_work = [&]() {
+        int wv = wave;
+        asm volatile("" : "+s"(wv));
+#pragma unroll
+        for (int i = 0; i < GW_RA; ++i) {
+            const int u = wv + 4 * i;
+            if (u < a_units) {
+                const int rg = (int)(((unsigned)u * inv_ncb) >> 16), cb = u - rg * ncb;
+                (smem + rg * rpu * g.AP + cb * 64)[lA] = ra[i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < GW_RB; ++i) {
+            const int u = wv + 4 * i;
+            if (u < b_units) {
+                const int rg = (int)(((unsigned)u * inv_ncb) >> 16), cb = u - rg * ncb;
+                (smem + rg * rpu * g.BP + cb * 64)[lB] = rb[i];
+            }
+        }
+    };
+
+    for (int i = tid; i < g.BP; i += 256) smem[zrow + i] = 0.f;
+    const int z = blockIdx.y, nz = gridDim.y;
+    const int tbeg = wt * (TC / g.WT), npair = TC / g.WT / 2;
+    load_work(z);
+    for (int w = z; w < g.nwork; w += nz) {
+        __syncthreads();                                     // the previous chunk's operand reads are done
+        store_work();
+        __syncthreads();
+        if (w + nz < g.nwork) load_work(w + nz);             // in flight while the matrix cores run this chunk
+        // software-pipelined position-pair loop, two pairs per trip with two operand sets (each read one MFMA group before
+        // its use); the read-ahead index is clamped (scalar) so it stays inside the row: AP, BP carry 2 positions of slack
+        const float* ap = smem + (wa * 32 + l31) * g.AP + half + tbeg;
+        const float* bp[NS];
+        float av = ap[0], bv[NS], an, bn[NS];
+#pragma unroll
+        for (int jt = 0; jt < NS; ++jt) { bp[jt] = smem + boff[jt] + tbeg; bv[jt] = bp[jt][0]; }
+        for (int p = 0; p < npair; p += 2) {
+            an = ap[2 * p + 2];
+#pragma unroll
+            for (int jt = 0; jt < NS; ++jt) bn[jt] = bp[jt][2 * p + 2];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int jt = 0; jt < NS; ++jt) acc[jt] = mfma32(av, bv[jt], acc[jt]);
+            __builtin_amdgcn_sched_barrier(0);
+            const int t2 = min(2 * p + 4, 2 * npair);
+            av = ap[t2];
+#pragma unroll
+            for (int jt = 0; jt < NS; ++jt) bv[jt] = bp[jt][t2];
+            __builtin_amdgcn_sched_barrier(0);
+            if (p + 1 < npair) {
+#pragma unroll
+                for (int jt = 0; jt < NS; ++jt) acc[jt] = mfma32(an, bn[jt], acc[jt]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (do_bias) {
+            const float* rp = smem + brow * g.AP + bpart * bcpp;
+            for (int c = 0; c < bcpp; ++c) bsum += rp[c];
         }
     }
+    __syncthreads();
+
+    // ---- waves that split the positions: sum in wave order (fixed), then the wt == 0 wave holds the tile
+    if (g.WT > 1) {
+        float* red = smem;                                   // [(WT-1)][waves with wt==0][NS][16][64]
+        const int owner = wa + WA * wj;                      // index among the wt == 0 waves
+        const int nown = WA * g.WJW;
+        if (wt > 0) {
 #pragma unroll
-    for (int k = 0; k < KMAX; ++k) {
-        if (k < K) {
+            for (int jt = 0; jt < NS; ++jt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) red[((((wt - 1) * nown + owner) * NS + jt) * 16 + r) * 64 + lane] = acc[jt][r];
+        }
+        __syncthreads();
+        if (wt == 0) {
+            for (int o = 0; o < g.WT - 1; ++o)
+#pragma unroll
+                for (int jt = 0; jt < NS; ++jt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[jt][r] += red[(((o * nown + owner) * NS + jt) * 16 + r) * 64 + lane];
+        }
+        __syncthreads();
+    }
+    if (wt == 0) {
+#pragma unroll
+        for (int jt = 0; jt < NS; ++jt) {
+            if (jt >= g.nsub) continue;
+            const int j = j0 + (wj * g.nsub + jt) * 32 + l31;
+            if (j >= g.NJ) continue;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int a = a0 + ma * 32 + mfma_row(r, half), b = b0 + mb * 32 + l31;
-                if (a < Ca && b < Cb) atomicAdd(G + ((size_t)a * Cb + b) * K + k, acc[k][r]);
+                const int a = a0 + wa * 32 + mfma_row(r, half);
+                if (a < g.Ca) g.slab[((size_t)z * g.Ca + a) * g.NJ + j] = acc[jt][r];
             }
         }
     }
-    if (dbias && blockIdx.y == 0 && a0 + (tid & 63) < Ca) atomicAdd(dbias + a0 + (tid & 63), bsum);
+    if (do_bias) {
+        float* bred = smem;                                  // [bparts][TA]
+        bred[bpart * TA + brow] = bsum;
+        __syncthreads();
+        if (bpart == 0 && a0 + brow < g.Ca) {
+            float sacc = 0.f;
+            for (int p = 0; p < bparts; ++p) sacc += bred[p * TA + brow];
+            g.slabb[(size_t)z * g.Ca + a0 + brow] = sacc;
+        }
+    }
+}
+
+// out[perm(i)] (+)= sum_z slab[z][i]: 8 z-lanes per output, each a fixed-order chain, combined in fixed order (fp64).
+//   remap 0: identity | 1: column j' = k*r1 + b -> b*r2 + k (tap planes -> dW[a][b][k]; r1 = Cb, r2 = K)
+//        | 2: column j' = (co*r1 + ph)*2 + q -> co*2*r1 + q*r1 + ph (stride phases -> ConvTranspose taps; r1 = stride)
+__global__ __launch_bounds__(256) void gwgrad2_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out, size_t n, int nz,
+                                                             int NJ, int accumulate, int remap, int r1, int r2) {
+    __shared__ double part[8][32];
+    const int o = threadIdx.x & 31, zl = threadIdx.x >> 5;
+    const size_t i = (size_t)blockIdx.x * 32 + o;
+    double s = 0.0;
+    if (i < n)
+        for (int z = zl; z < nz; z += 8) s += (double)slab[(size_t)z * n + i];
+    part[zl][o] = s;
+    __syncthreads();
+    if (zl == 0 && i < n) {
+        double t = 0.0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) t += part[q][o];
+        size_t d = i;
+        if (remap) {
+            const size_t a = i / (size_t)NJ;
+            const int jp = (int)(i - a * (size_t)NJ);
+            int j;
+            if (remap == 1) { const int k = jp / r1, b = jp - k * r1; j = b * r2 + k; }
+            else { const int q2 = jp & 1, cp = jp >> 1, co = cp / r1, ph = cp - co * r1; j = co * 2 * r1 + q2 * r1 + ph; }
+            d = a * (size_t)NJ + j;
+        }
+        out[d] = (float)((accumulate ? (double)out[d] : 0.0) + t);
+    }
+}
+
+// y[nb][row][t] = x[nb][c][t*S + k - P] (0 outside the clip), t in [0, Lout), for c < C, k < K:
+//   order 0: row = k*C + c (tap planes: a strided Conv1d's weight gradient becomes a K = 1 GEMM, and its 1x1 strided
+//            skip convolution reads plane P);  order 1: row = c*K + k (stride phases of a ConvTranspose1d's output gradient)
+__global__ __launch_bounds__(256) void gather_taps_kernel(const float* __restrict__ x, float* __restrict__ y, int C, int Lin, int K,
+                                                          int S, int P, int Lout, int order) {
+    const int t = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y, nb = blockIdx.z;
+    if (t >= Lout) return;
+    const float* xr = x + ((size_t)nb * C + c) * Lin;
+    float* yb = y + (size_t)nb * C * K * Lout;
+    for (int k = 0; k < K; ++k) {
+        const int u = t * S + k - P;
+        const float v = (u >= 0 && u < Lin) ? xr[u] : 0.f;
+        const int row = order ? c * K + k : k * C + c;
+        yb[(size_t)row * Lout + t] = v;
+    }
+}
+
+template <int WA, int NS>
+int launch_gwgrad2(const GWArgs& g, dim3 grid, size_t lds, hipStream_t stream) {
+    auto kern = gwgrad2_kernel<WA, NS>;
+    static wm::DevOnce once;
+    if (!wm::dev_done(once)) {
+        WM_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        wm::dev_mark(once);
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, g);
+    WM_CHECK_LAUNCH();
+    return 0;
+}
+
+struct GWPlan {
+    bool ok;
+    int WA, TC, nchunks, nsub, WJW, WT, ntj, nta, NBCH, ncb, AP, BP, gz;
+    size_t lds, slab_floats;
+};
+
+GWPlan gw_plan(int NB, int Ca, int Cb, int La, int K) {
+    GWPlan p{};
+    p.WA = Ca > 32 ? 2 : 1;
+    const int TA = 32 * p.WA, R = 4 / p.WA, NJ = Cb * K;
+    p.nta = (Ca + TA - 1) / TA;
+    const int nsub_total = (NJ + 31) / 32;
+    p.WJW = 1;
+    while (p.WJW < R && nsub_total > 4 * p.WJW) p.WJW *= 2;
+    p.nsub = (nsub_total + p.WJW - 1) / p.WJW;
+    if (p.nsub > 4) p.nsub = 4;
+    p.WT = R / p.WJW;
+    for (;;) {                                              // K = 1: every column is its own channel -- bound the rows staged
+        const int TJ = p.WJW * 32 * p.nsub;
+        p.NBCH = (TJ - 1) / K + 2;
+        if (p.NBCH > Cb) p.NBCH = Cb;
+        if (p.NBCH <= 128 || p.nsub == 1) break;
+        --p.nsub;
+    }
+    const int TJ = p.WJW * 32 * p.nsub;
+    p.ntj = (NJ + TJ - 1) / TJ;
+    const int ra = Ca < TA ? Ca : TA, rbx = p.NBCH;          // rows staged per chunk
+    // positions per chunk: ncb blocks of 64 (one block of 32 for short sequences); few rows -> long chunks (up to 256)
+    for (int ncb = 4; ncb >= 1 && !p.ok; --ncb) {
+        for (int narrow = 0; narrow < 2 && !p.ok; ++narrow) {
+            if (narrow && ncb > 1) continue;
+            const int width = narrow ? 32 : 64 * ncb;            // staged span of a row
+            int tcmax = (width - (K - 1)) & ~7;                  // so that BW = TC + K - 1 <= width
+            if (tcmax < 8) continue;
+            if (!narrow && ncb > 1 && La < 64 * (ncb - 1)) continue;
+            if (!narrow && ncb == 1 && La <= 24) continue;       // short sequences: the 32-wide form wastes fewer lanes
+            p.nchunks = (La + tcmax - 1) / tcmax;
+            p.TC = (((La + p.nchunks - 1) / p.nchunks) + 7) & ~7;
+            if (p.TC > tcmax) p.TC = tcmax;
+            p.nchunks = (La + p.TC - 1) / p.TC;
+            const int BW = p.TC + K - 1, rpu = BW <= 32 ? 2 : 1;
+            if ((rpu == 2) != (narrow == 1)) continue;
+            const int a_units = ((ra + rpu - 1) / rpu) * ncb, b_units = ((rbx + rpu - 1) / rpu) * ncb;
+            // pitches: whole staging units wide (unconditional stores) + slack for the pipelined loop's read-ahead (2 positions);
+            // A: odd (operand read down a column); Bx: == K (mod 32), so tile column j reads bank j
+            p.AP = (width + 2) | 1;
+            const int bpw = width + 2;
+            p.BP = bpw + (((K - bpw) % 32) + 32) % 32;
+            size_t lds = ((size_t)TA * p.AP + (size_t)(p.NBCH + 1) * p.BP) * sizeof(float);
+            const size_t red = (size_t)(p.WT - 1) * p.WA * p.WJW * 4 * 16 * 64 * sizeof(float);
+            if (red > lds) lds = red;
+            if (lds < 1024 * sizeof(float)) lds = 1024 * sizeof(float);
+            if (a_units <= 4 * GW_RA && b_units <= 4 * GW_RB && lds <= 50 * 1024) { p.lds = lds; p.ncb = ncb; p.ok = true; }
+        }
+    }
+    if (!p.ok) return p;
+    const long long nwork = (long long)NB * p.nchunks;
+    const int tiles = p.nta * p.ntj;
+    long long gz = tiles >= 768 ? 1 : 768 / tiles;          // ~768 workgroups = three per CU (what LDS and registers admit)
+    if (gz > nwork) gz = nwork;
+    if (gz > 256) gz = 256;
+    if (gz < 1) gz = 1;
+    p.gz = (int)gz;
+    p.slab_floats = (size_t)p.gz * Ca * (NJ + 1);           // [gz][Ca][NJ] then [gz][Ca] bias partials
+    return p;
 }
 
 // dz = g * elu'(y) with y = ELU(z):  elu'(z) = 1 for y > 0 else y + 1   (alpha = 1)
@@ -289,6 +801,120 @@ __global__ void rows_scatter_add_kernel(float* __restrict__ dtable, const long l
     atomicAdd(dtable + (size_t)m * dim + (i % dim), dvec[i]);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// nn.LSTM(hd, hd, num_layers=2) over the T = 50 latent steps (py/main14b_2.py:137, :165): the recurrence of ONE layer as
+// a chain of per-step launches issued back to back by the C launcher (no host work between them; the kernel boundary is
+// the step barrier, so no grid-wide spin and nothing that can hang).  Layouts: time-major, batch contiguous.
+//
+// forward step:  gates[q*H + u][b] = xp[q*H + u][b] + sum_k W_hh[q*H + u][k] * h_prev[k][b];  cell update.
+//   workgroup = 8 units x 4 gates (32 gate rows) x 32 batch columns; its 4 waves split the contraction (K = H): lane
+//   (i, half) of wave w owns k = w*H/4 + half*H/8 + s, s < H/8 -- a contiguous run of ITS weight row, so the A operand is
+//   H/32 float4 loads straight from the PyTorch weight (no transpose, no LDS); the B operand rows are 128-byte coalesced.
+//   All loads are issued up front, then H/8 MFMAs per wave; partial tiles are summed through LDS in wave order.
+__global__ __launch_bounds__(256) void lstm_seq_fwd_kernel(const float* xp, const float* __restrict__ whh,
+                                                           const float* __restrict__ hprev, const float* __restrict__ cprev,
+                                                           float* __restrict__ hout, float* __restrict__ cout, float* gates_out,
+                                                           int H, int Bn) {
+    constexpr int MAXS = 32;                     // H/8 <= 32  (H <= 256)
+    __shared__ float red[4][16][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const int u0 = blockIdx.x * 8, b0 = blockIdx.y * 32;
+    const int SL = H >> 3;                       // contraction values per lane
+    const int grow = (l31 >> 3) * H + u0 + (l31 & 7);                  // this lane's gate row (A operand row)
+    const int kbase = wave * (H >> 2) + half * SL;
+    const int bcol = min(b0 + l31, Bn - 1);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    if (hprev) {
+        f32x4 a4[MAXS / 4];
+        float bv[MAXS];
+        const float* wr = whh + (size_t)grow * H + kbase;
+#pragma unroll
+        for (int i = 0; i < MAXS / 4; ++i)
+            if (4 * i < SL) a4[i] = *reinterpret_cast<const f32x4*>(wr + 4 * i);
+#pragma unroll
+        for (int s = 0; s < MAXS; ++s)
+            if (s < SL) bv[s] = hprev[(size_t)(kbase + s) * Bn + bcol];
+#pragma unroll
+        for (int s = 0; s < MAXS; ++s)
+            if (s < SL) acc = mfma32(a4[s >> 2][s & 3], bv[s], acc);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
+    __syncthreads();
+    // cell update: thread = (unit, batch column); gate q of unit u is tile row q*8 + u = register (row&3) + 4*((row>>3)&3)... of lane half
+    const int u = tid >> 5, bl = tid & 31, b = b0 + bl;
+    if (b >= Bn) return;
+    float pre[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int row = q * 8 + u;               // D row = (r&3) + 8*(r>>2) + 4*half
+        const int hf = (row >> 2) & 1, r = (row & 3) + 4 * (row >> 3);
+        const int ln = hf * 32 + bl;
+        pre[q] = ((red[0][r][ln] + red[1][r][ln]) + red[2][r][ln]) + red[3][r][ln] + xp[(size_t)(q * H + u0 + u) * Bn + b];
+    }
+    const float gi = 1.f / (1.f + expf(-pre[0])), gf = 1.f / (1.f + expf(-pre[1])), gg = tanhf(pre[2]), go = 1.f / (1.f + expf(-pre[3]));
+    const size_t o = (size_t)(u0 + u) * Bn + b;
+    const float cp = cprev ? cprev[o] : 0.f;
+    const float c = gf * cp + gi * gg;
+    hout[o] = go * tanhf(c);
+    cout[o] = c;
+    if (gates_out) {
+        gates_out[(size_t)(0 * H + u0 + u) * Bn + b] = gi; gates_out[(size_t)(1 * H + u0 + u) * Bn + b] = gf;
+        gates_out[(size_t)(2 * H + u0 + u) * Bn + b] = gg; gates_out[(size_t)(3 * H + u0 + u) * Bn + b] = go;
+    }
+}
+
+// backward step:  dh[u][b] = dout[u][b] + sum_g W_hh[g][u] * da_next[g][b]  (K = 4H), then the pointwise gate backward:
+//   gates (activations) -> da (in place), dc (in/out).  Workgroup = 16 units x 16 batch columns (fp32 MFMA 16x16x4), its 4
+//   waves split K; lane (i, kq) of wave w owns g = w*H + kq*H/4 + s, s < H/4 -- contiguous in the TRANSPOSED weight whhT
+//   [H][4H] (float4 loads); the B operand rows are 64-byte segments of da_next.
+__global__ __launch_bounds__(256) void lstm_seq_bwd_kernel(float* gates, const float* __restrict__ danext, const float* __restrict__ whhT,
+                                                           const float* __restrict__ c, const float* __restrict__ cprev,
+                                                           const float* __restrict__ dout, float* __restrict__ dc, int H, int Bn) {
+    constexpr int MAXS = 64;                     // H/4 <= 64
+    __shared__ float red[4][4][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kq = lane >> 4, l15 = lane & 15;
+    const int u0 = blockIdx.x * 16, b0 = blockIdx.y * 16;
+    const int SL = H >> 2;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (danext) {
+        const int gbase = wave * H + kq * SL;
+        const int bcol = min(b0 + l15, Bn - 1);
+        const float* wr = whhT + (size_t)(u0 + l15) * 4 * H + gbase;
+        f32x4 a4[MAXS / 4];
+        float bv[MAXS];
+#pragma unroll
+        for (int i = 0; i < MAXS / 4; ++i)
+            if (4 * i < SL) a4[i] = *reinterpret_cast<const f32x4*>(wr + 4 * i);
+#pragma unroll
+        for (int s = 0; s < MAXS; ++s)
+            if (s < SL) bv[s] = danext[(size_t)(gbase + s) * Bn + bcol];
+#pragma unroll
+        for (int s = 0; s < MAXS; ++s)
+            if (s < SL) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[s >> 2][s & 3], bv[s], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wave][r][lane] = acc[r];
+    __syncthreads();
+    const int ul = tid >> 4, bl = tid & 15, b = b0 + bl;       // D: col = lane&15, row = (lane>>4)*4 + reg
+    if (b >= Bn) return;
+    const int r = ul & 3, ln = (ul >> 2) * 16 + bl;
+    const size_t o = (size_t)(u0 + ul) * Bn + b, hb = (size_t)H * Bn;
+    const float dht = ((red[0][r][ln] + red[1][r][ln]) + red[2][r][ln]) + red[3][r][ln] + dout[o];
+    const float gi = gates[o], gf = gates[hb + o], gg = gates[2 * hb + o], go = gates[3 * hb + o];
+    const float tc = tanhf(c[o]);
+    const float dct = dc[o] + dht * go * (1.f - tc * tc);
+    const float cp = cprev ? cprev[o] : 0.f;
+    gates[o] = dct * gg * gi * (1.f - gi);
+    gates[hb + o] = dct * cp * gf * (1.f - gf);
+    gates[2 * hb + o] = dct * gi * (1.f - gg * gg);
+    gates[3 * hb + o] = dht * tc * go * (1.f - go);
+    dc[o] = dct * gf;
+}
+
 }  // namespace
 
 extern "C" {
@@ -298,13 +924,23 @@ extern "C" {
 int wm_gconv(const float* x, const float* wp, const float* bias, const float* vec, const float* res, float* y, int NB,
              int Cin, int Lin, int K, int S, int P, int Mtot, int Nout, int st, int shp, int Cout, int Lout, int act,
              hipStream_t stream) {
-    if (NB <= 0 || Cin <= 0 || K <= 0 || K > 16 || S <= 0 || S > 8 || Mtot <= 0 || Nout <= 0 || st < 1) return (int)hipErrorInvalidValue;
-    GConvArgs a{x, wp, bias, vec, res, y, NB, Cin, Lin, K, S, P, Mtot, Nout, st, shp, Cout, Lout, act};
-    const size_t lds = (size_t)(GC * (63 * S + K) + GC * K * 64 + GC * K) * sizeof(float);
-    dim3 grid((Nout + 63) / 64, (Mtot + 63) / 64, NB);
-    hipLaunchKernelGGL(gconv_kernel, grid, dim3(256), lds, stream, a);
-    WM_CHECK_LAUNCH();
-    return 0;
+    if (NB <= 0 || Cin <= 0 || K <= 0 || K > 16 || S <= 0 || S > 8 || Mtot <= 0 || Nout <= 0 || st < 1 || Lin <= 0 ||
+        Lin >= (1 << 24) || NB > 65535)
+        return (int)hipErrorInvalidValue;
+    GConvArgs a{x, wp, bias, vec, res, y, NB, Cin, Lin, K, S, P, Mtot, Nout, st, shp, Cout, Lout, act, 0, 0};
+    const bool vec4 = (Mtot % 4 == 0) && ((reinterpret_cast<uintptr_t>(wp) & 15) == 0);
+    // tile shape by problem shape: (rows, columns) = (128,128) | (64,128) | (32,256); short sequences (<= 64): (128,64) | (64,64)
+    if (!vec4) {
+        if (Mtot > 32) return (int)hipErrorInvalidValue;     // unaligned weight rows: only the narrow heads (1 / 17 channels)
+        return launch_gconv2<1, 1, 2, false>(a, stream);
+    }
+    int rc;
+    if (Nout <= 64) rc = Mtot > 64 ? launch_gconv2<2, 2, 1, true>(a, stream) : launch_gconv2<2, 1, 1, true>(a, stream);
+    else if (Mtot > 64) rc = launch_gconv2<2, 2, 2, true>(a, stream);
+    else if (Mtot > 32) rc = launch_gconv2<2, 1, 2, true>(a, stream);
+    else rc = launch_gconv2<1, 1, 2, true>(a, stream);
+    if (rc == (int)hipErrorInvalidValue) rc = launch_gconv2<2, 1, 1, true>(a, stream);   // widest-stride shapes: the narrowest input tile
+    return rc;
 }
 
 int wm_permute_acl(const float* x, float* y, int A, int C, int L, hipStream_t stream) {
@@ -314,33 +950,57 @@ int wm_permute_acl(const float* x, float* y, int A, int C, int L, hipStream_t st
     return 0;
 }
 
-// G[a][b][k] += sum_{nb,t} A[nb][a][t] * Bx[nb][b][t*S + k - P]; dbias[a] += sum A (dbias may be NULL).  ACCUMULATES
-// (float atomics): the caller zeroes G / dbias.  K <= 16.
-int wm_gwgrad(const float* A, const float* Bx, float* G, float* dbias, int NB, int Ca, int Cb, int La, int Lb, int K, int S,
-              int P, hipStream_t stream) {
-    if (NB <= 0 || Ca <= 0 || Cb <= 0 || La <= 0 || K <= 0 || K > 16 || S <= 0 || S > 8) return (int)hipErrorInvalidValue;
-    int TC = 256;                                  // positions per LDS chunk: two workgroups of <= 78 KB per CU
-    auto lds_of = [&](int tc) { return (size_t)(64 * (tc + 1) + 64 * (((tc - 1) * S + K) | 1)) * sizeof(float); };
-    while (TC > 64 && lds_of(TC) > 78 * 1024) TC >>= 1;
-    if (La <= 64) TC = 64;
-    const int nchunks = (La + TC - 1) / TC, nwork = NB * nchunks;
-    const int tiles = ((Ca + 63) / 64) * ((Cb + 63) / 64);
-    int gz = (1024 + tiles - 1) / tiles;          // ~1024 workgroups in flight overall (2 per CU, twice over)
-    if (gz > nwork) gz = nwork;
-    if (gz < 1) gz = 1;
-    const size_t lds = lds_of(TC);
-    if (lds > 150 * 1024) return (int)hipErrorInvalidValue;
-    dim3 grid((Ca + 63) / 64, (Cb + 63) / 64, gz);
-    static wm::DevOnce done;
-    if (!wm::dev_done(done)) {
-        WM_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gwgrad_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        WM_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gwgrad_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        WM_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gwgrad_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        wm::dev_mark(done);
+// workspace of wm_gwgrad for a problem shape: *slab_floats = number of fp32 elements the caller must provide
+int wm_gwgrad_plan(int NB, int Ca, int Cb, int La, int K, long long* slab_floats, hipStream_t) {
+    if (NB <= 0 || Ca <= 0 || Cb <= 0 || La <= 0 || K <= 0 || K > 16 || !slab_floats) return (int)hipErrorInvalidValue;
+    const GWPlan p = gw_plan(NB, Ca, Cb, La, K);
+    if (!p.ok) return (int)hipErrorInvalidValue;
+    *slab_floats = (long long)p.slab_floats;
+    return 0;
+}
+
+// G[a][b][k] (+)= sum_{nb,t} A[nb][a][t] * Bx[nb][b][t + k - P]; dbias[a] (+)= sum A (dbias may be NULL).  Deterministic
+// (split-K partial tiles in `slab`, >= wm_gwgrad_plan floats, then a fixed-order reduce).  accumulate: 0 overwrite | 1 add.
+// b_clip_stride: floats between clips of Bx (0 = dense, Cb*Lb); remap / r1 / r2: column order of the result (see the reduce).
+int wm_gwgrad(const float* A, const float* Bx, float* G, float* dbias, float* slab, int NB, int Ca, int Cb, int La, int Lb,
+              int K, int P, long long b_clip_stride, int remap, int r1, int r2, int accumulate, hipStream_t stream) {
+    if (NB <= 0 || Ca <= 0 || Cb <= 0 || La <= 0 || Lb <= 0 || K <= 0 || K > 16 || !slab || remap < 0 || remap > 2 ||
+        (size_t)Ca * La >= (1u << 30) || (size_t)Cb * Lb >= (1u << 30))
+        return (int)hipErrorInvalidValue;
+    if (b_clip_stride == 0) b_clip_stride = (long long)Cb * Lb;
+    if (b_clip_stride < (long long)Cb * Lb) return (int)hipErrorInvalidValue;
+    const int NJ = Cb * K;
+    if ((remap == 1 && (r1 <= 0 || r2 <= 0 || r1 * r2 != NJ)) || (remap == 2 && (r1 <= 0 || K != 2 || Cb % r1 != 0)))
+        return (int)hipErrorInvalidValue;
+    const GWPlan p = gw_plan(NB, Ca, Cb, La, K);
+    if (!p.ok) return (int)hipErrorInvalidValue;
+    float* slabb = dbias ? slab + (size_t)p.gz * Ca * NJ : nullptr;
+    GWArgs g{A, Bx, slab, slabb, NB, Ca, Cb, La, Lb, K, P, b_clip_stride, NJ, p.TC, p.nchunks, p.nsub, p.WJW, p.WT, p.ntj, p.NBCH,
+             p.ncb, p.AP, p.BP, NB * p.nchunks};
+    dim3 grid(p.nta * p.ntj, p.gz);
+    const int ns = p.nsub == 1 ? 1 : (p.nsub == 2 ? 2 : 4);
+    int rc = 0;
+    if (p.WA == 1) rc = ns == 1 ? launch_gwgrad2<1, 1>(g, grid, p.lds, stream) : ns == 2 ? launch_gwgrad2<1, 2>(g, grid, p.lds, stream)
+                                                                                          : launch_gwgrad2<1, 4>(g, grid, p.lds, stream);
+    else rc = ns == 1 ? launch_gwgrad2<2, 1>(g, grid, p.lds, stream) : ns == 2 ? launch_gwgrad2<2, 2>(g, grid, p.lds, stream)
+                                                                                : launch_gwgrad2<2, 4>(g, grid, p.lds, stream);
+    if (rc) return rc;
+    const size_t n = (size_t)Ca * NJ;
+    hipLaunchKernelGGL(gwgrad2_reduce_kernel, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, stream, slab, G, n, p.gz, NJ, accumulate,
+                       remap, r1, r2);
+    WM_CHECK_LAUNCH();
+    if (dbias) {
+        hipLaunchKernelGGL(gwgrad2_reduce_kernel, dim3((unsigned)((Ca + 31) / 32)), dim3(256), 0, stream, slabb, dbias, (size_t)Ca,
+                           p.gz, Ca, accumulate, 0, 0, 0);
+        WM_CHECK_LAUNCH();
     }
-    if (K <= 4) hipLaunchKernelGGL(gwgrad_kernel<4>, grid, dim3(256), lds, stream, A, Bx, G, dbias, NB, Ca, Cb, La, Lb, K, S, P, TC);
-    else if (K <= 8) hipLaunchKernelGGL(gwgrad_kernel<8>, grid, dim3(256), lds, stream, A, Bx, G, dbias, NB, Ca, Cb, La, Lb, K, S, P, TC);
-    else hipLaunchKernelGGL(gwgrad_kernel<16>, grid, dim3(256), lds, stream, A, Bx, G, dbias, NB, Ca, Cb, La, Lb, K, S, P, TC);
+    return 0;
+}
+
+// y[nb][row][t] = x[nb][c][t*S + k - P] (0 outside), t < Lout; order 0: row = k*C + c | 1: row = c*K + k   (see gather_taps_kernel)
+int wm_gather_taps(const float* x, float* y, int NB, int C, int Lin, int K, int S, int P, int Lout, int order, hipStream_t stream) {
+    if (NB <= 0 || NB > 65535 || C <= 0 || C > 65535 || Lin <= 0 || K <= 0 || S <= 0 || Lout <= 0) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(gather_taps_kernel, dim3((Lout + 255) / 256, C, NB), dim3(256), 0, stream, x, y, C, Lin, K, S, P, Lout, order);
     WM_CHECK_LAUNCH();
     return 0;
 }
@@ -382,6 +1042,39 @@ int wm_lstm_h_step_fwd(const float* xp, const float* whhT, const float* hprev, c
     if (H <= 0 || (H & 31) || Bn <= 0) return (int)hipErrorInvalidValue;
     hipLaunchKernelGGL(lstm_h_step_fwd_kernel, dim3(H / 32, (Bn + 31) / 32), dim3(64), 0, stream, xp, whhT, hprev, cprev, hout,
                        cout, gates_out, H, Bn);
+    WM_CHECK_LAUNCH();
+    return 0;
+}
+
+// One layer of nn.LSTM(H, H) over T steps, zero initial state (py/main14b_2.py:165).  xp [T][4H][B] = W_ih x_t + b_ih + b_hh
+// (overwritten in place by the gate activations when save != 0 -- what wm_lstm_seq_bwd consumes); whh = weight_hh [4H][H];
+// hs, cs [T+1][H][B] with hs[0] / cs[0] = 0 provided by the caller: h_t = hs[t+1].  T launches, issued back to back.
+int wm_lstm_seq_fwd(float* xp, const float* whh, float* hs, float* cs, int T, int H, int B, int save, hipStream_t stream) {
+    if (T <= 0 || H <= 0 || (H & 31) || H > 256 || B <= 0) return (int)hipErrorInvalidValue;
+    const size_t hb = (size_t)H * B;
+    dim3 grid(H / 8, (B + 31) / 32);
+    for (int t = 0; t < T; ++t) {
+        float* g = xp + (size_t)t * 4 * hb;
+        hipLaunchKernelGGL(lstm_seq_fwd_kernel, grid, dim3(256), 0, stream, g, whh, t ? hs + (size_t)t * hb : nullptr,
+                           t ? cs + (size_t)t * hb : nullptr, hs + (size_t)(t + 1) * hb, cs + (size_t)(t + 1) * hb, save ? g : nullptr, H, B);
+    }
+    WM_CHECK_LAUNCH();
+    return 0;
+}
+
+// BPTT of that layer: gates [T][4H][B] (activations in, pre-activation gradients da out, in place), cs as written by the
+// forward, dout [T][H][B] = dL/dh_t from above, whhT = weight_hh^T [H][4H], dc [H][B] scratch (zeroed here).  T launches.
+int wm_lstm_seq_bwd(float* gates, const float* cs, const float* dout, const float* whhT, float* dc, int T, int H, int B,
+                    hipStream_t stream) {
+    if (T <= 0 || H <= 0 || (H & 31) || H > 256 || B <= 0) return (int)hipErrorInvalidValue;
+    const size_t hb = (size_t)H * B;
+    WM_TRY(hipMemsetAsync(dc, 0, hb * sizeof(float), stream));
+    dim3 grid(H / 16, (B + 15) / 16);
+    for (int t = T - 1; t >= 0; --t) {
+        hipLaunchKernelGGL(lstm_seq_bwd_kernel, grid, dim3(256), 0, stream, gates + (size_t)t * 4 * hb,
+                           t + 1 < T ? gates + (size_t)(t + 1) * 4 * hb : nullptr, whhT, cs + (size_t)(t + 1) * hb,
+                           t ? cs + (size_t)t * hb : nullptr, dout + (size_t)t * hb, dc, H, B);
+    }
     WM_CHECK_LAUNCH();
     return 0;
 }

@@ -11,6 +11,8 @@ layout.  Forward AND backward run in csrc/gconv.hip:
 """
 from __future__ import annotations
 
+import ctypes
+
 import torch
 import torch.nn as nn
 
@@ -54,11 +56,49 @@ def _conv_dgrad(g, w, stride, padding, Lin):
     return _gconv_raw(g, wp, None, Kg, 1, Kg - 1, Cin * stride, Nout, stride, padding, Cin, Lin)
 
 
-def _gwgrad(A, Bx, shape, K, S, P, want_bias):
-    G = torch.zeros(shape, dtype=torch.float32, device=A.device)
-    db = torch.zeros(A.shape[1], dtype=torch.float32, device=A.device) if want_bias else None
-    lib.wm_gwgrad(_p(A), _p(Bx), _p(G), _p(db), A.shape[0], A.shape[1], Bx.shape[1], A.shape[2], Bx.shape[2], K, S, P, _stream())
+_PLAN = {}
+
+
+def _gwgrad_workspace(NB, Ca, Cb, La, K, device):
+    """split-K partial-tile workspace of wm_gwgrad for this problem shape (size from the library's own plan)"""
+    key = (NB, Ca, Cb, La, K)
+    if key not in _PLAN:
+        out = (ctypes.c_longlong * 1)()
+        lib.wm_gwgrad_plan(NB, Ca, Cb, La, K, ctypes.addressof(out), None)
+        _PLAN[key] = int(out[0])
+    return _f32(_PLAN[key], device=device)
+
+
+def _gwgrad_raw(A, Bx, Cb, Lb, b_clip_stride, shape, K, P, want_bias, remap=0, r1=0, r2=0):
+    """G[a][b][k] = sum_{nb,t} A[nb][a][t] * Bx[nb][b][t + k - P] (+ dbias[a] = sum A): deterministic split-K GEMM.
+    Bx is a raw view (Cb channels of Lb floats per clip, clips b_clip_stride floats apart)."""
+    NB, Ca, La = A.shape
+    G = torch.empty(shape, dtype=torch.float32, device=A.device)
+    db = _f32(Ca, device=A.device) if want_bias else None
+    slab = _gwgrad_workspace(NB, Ca, Cb, La, K, A.device)
+    lib.wm_gwgrad(_p(A), _p(Bx), _p(G), _p(db), _p(slab), NB, Ca, Cb, La, Lb, K, P, b_clip_stride, remap, r1, r2, 0, _stream())
     return G, db
+
+
+def _gather_taps(x, K, S, P, Lout, order):
+    """[NB][C][Lin] -> [NB][K*C | C*K][Lout]: tap planes (order 0) / stride phases (order 1) as channels"""
+    NB, C, Lin = x.shape
+    y = _f32(NB, C * K, Lout, device=x.device)
+    lib.wm_gather_taps(_p(x), _p(y), NB, C, Lin, K, S, P, Lout, order, _stream())
+    return y
+
+
+def _conv_wgrad(gz, x, w_shape, stride, padding, want_bias, planes=None):
+    """dW (and db) of Conv1d(w [Cout,Cin,K], stride, padding) for dL/dy = gz and input x.  A strided convolution first lays
+    the K tap planes of x out as channels (x'[k*Cin + ci][t] = x[ci][t*stride + k - padding]): its weight gradient is then a
+    K = 1 stride-1 GEMM over K*Cin channels (`planes` = an already gathered x', shared with the block's 1x1 skip conv)."""
+    Cout, Cin, K = w_shape
+    if stride == 1:
+        return _gwgrad_raw(gz, x, Cin, x.shape[2], 0, w_shape, K, padding, want_bias)
+    Lout = gz.shape[2]
+    if planes is None:
+        planes = _gather_taps(x, K, stride, padding, Lout, 0)
+    return _gwgrad_raw(gz, planes, K * Cin, Lout, 0, w_shape, 1, 0, want_bias, 1, Cin, K)
 
 
 def _elu_bwd(g, y):
@@ -87,7 +127,7 @@ class ConvFn(torch.autograd.Function):
         gy = gy.contiguous()
         gz = _elu_bwd(gy, y) if act else gy
         dx = _conv_dgrad(gz, w, stride, padding, x.shape[2]) if ctx.needs_input_grad[0] else None
-        dw, db = _gwgrad(gz, x, w.shape, w.shape[2], stride, padding, True)
+        dw, db = _conv_wgrad(gz, x, w.shape, stride, padding, True)
         dvec = None
         if has_vec:
             dvec = _f32(gz.shape[0], gz.shape[1], device=gz.device)
@@ -120,7 +160,10 @@ class ConvTFn(torch.autograd.Function):
         # dx[ci][j] = sum_{co,k} g[co][j*st - pad + k] W[ci][co][k]: a strided conv over g
         wp = w.permute(1, 2, 0).reshape(Cout * K, Cin).contiguous()
         dx = _gconv_raw(g, wp, None, K, st, pad, Cin, x.shape[2], 1, 0, Cin, x.shape[2])
-        dw, _ = _gwgrad(x, g, w.shape, K, st, pad, False)
+        # dW[ci][co][q*st + ph] = sum_t x[ci][t] * g'[co*st + ph][t + q] with the stride phases of g as channels:
+        # a K = 2 stride-1 GEMM over Cout*st channels
+        gp = _gather_taps(g, st, st, pad, x.shape[2] + 1, 1)
+        dw, _ = _gwgrad_raw(x, gp, Cout * st, x.shape[2] + 1, 0, w.shape, 2, 0, False, 2, st, 0)
         db = torch.zeros(Cout, dtype=torch.float32, device=g.device)
         lib.wm_channel_sum(_p(g), _p(db), g.shape[0], Cout, g.shape[2], _stream())
         return dx, dw, db, None
@@ -166,7 +209,8 @@ class RowsGatherFn(torch.autograd.Function):
 
 
 class LSTMLayerFn(ops.GradAwareFunction):
-    """one layer of nn.LSTM(H, H) on a time-major sequence [T][H][B] (zero initial state)"""
+    """one layer of nn.LSTM(H, H) on a time-major sequence [T][H][B] (zero initial state): the input projection of all steps
+    is one GEMM, the recurrence a chain of T per-step launches issued by the C launcher (wm_lstm_seq_fwd / _bwd)"""
 
     @staticmethod
     def forward(ctx, seq, w_ih, w_hh, b_ih, b_hh):
@@ -175,17 +219,13 @@ class LSTMLayerFn(ops.GradAwareFunction):
         dev, st = seq.device, _stream()
         bias = (b_ih + b_hh).contiguous()
         xp = _gconv_raw(seq, w_ih.t().contiguous(), bias, 1, 1, 0, 4 * H, B, 1, 0, 4 * H, B)     # [T][4H][B]
-        whhT = w_hh.t().contiguous()
         need = ops.wants_grad(ctx)
         hs = _f32(T + 1, H, B, device=dev)           # hs[t+1] = h_t, hs[0] = 0 (so hs[:T] is the h_{t-1} sequence)
         cs = _f32(T + 1, H, B, device=dev)
         hs[0].zero_(); cs[0].zero_()
-        gates = xp if need else None                 # activations overwrite the projections in place
-        for t in range(T):
-            lib.wm_lstm_h_step_fwd(_p(xp[t]), _p(whhT), _p(hs[t]), _p(cs[t]), _p(hs[t + 1]), _p(cs[t + 1]),
-                                   _p(gates[t]) if need else None, H, B, st)
+        lib.wm_lstm_seq_fwd(_p(xp), _p(w_hh.contiguous()), _p(hs), _p(cs), T, H, B, 1 if need else 0, st)
         if need:
-            ctx.save_for_backward(seq, hs, cs, gates, w_ih, w_hh)
+            ctx.save_for_backward(seq, hs, cs, xp, w_ih, w_hh)      # xp now holds the gate activations
         return hs[1:]
 
     @staticmethod
@@ -195,17 +235,12 @@ class LSTMLayerFn(ops.GradAwareFunction):
         dout = dout.contiguous()
         T, H, B = seq.shape
         dev, st = seq.device, _stream()
-        dc = torch.zeros(H, B, dtype=torch.float32, device=dev)
-        wpr = w_hh.contiguous()                      # [4H][H] = gconv image for dh_{t-1} = W_hh^T da_t
-        dh = dout[T - 1]
-        for t in range(T - 1, -1, -1):
-            lib.wm_lstm_h_step_bwd(_p(gates[t]), _p(cs[t + 1]), _p(cs[t]), _p(dh), _p(dc), H, B, st)   # gates[t] -> da_t
-            if t > 0:
-                dh = _gconv_raw(gates[t].unsqueeze(0), wpr, None, 1, 1, 0, H, B, 1, 0, H, B, 0, dout[t - 1].unsqueeze(0))[0]
+        dc = _f32(H, B, device=dev)
+        lib.wm_lstm_seq_bwd(_p(gates), _p(cs), _p(dout), _p(w_hh.t().contiguous()), _p(dc), T, H, B, st)   # gates -> da
         da = gates                                   # [T][4H][B]
         dx = _gconv_raw(da, w_ih.contiguous(), None, 1, 1, 0, H, B, 1, 0, H, B) if ctx.needs_input_grad[0] else None
-        dwi, db = _gwgrad(da, seq, (4 * H, H, 1), 1, 1, 0, True)
-        dwh, _ = _gwgrad(da, hs[:T], (4 * H, H, 1), 1, 1, 0, False)
+        dwi, db = _gwgrad_raw(da, seq, H, B, 0, (4 * H, H, 1), 1, 0, True)
+        dwh, _ = _gwgrad_raw(da, hs[:T], H, B, 0, (4 * H, H, 1), 1, 0, False)
         return dx, dwi.reshape(4 * H, H), dwh.reshape(4 * H, H), db, db.clone()
 
 

@@ -175,11 +175,20 @@ int wm_adam_step(float* p, const float* g, float* m, float* v, long long n, doub
 int wm_gconv(const float* x, const float* wp, const float* bias, const float* vec, const float* res, float* y, int NB,
              int Cin, int Lin, int K, int S, int P, int Mtot, int Nout, int st, int shp, int Cout, int Lout, int act,
              wm_stream_t stream);
-/* generic weight gradient (ACCUMULATES with float atomics; caller zeroes G/dbias):
- *   G[a][b][k] += sum_{nb,t} A[nb][a][t] * Bx[nb][b][t*S + k - P],  dbias[a] += sum A   (Conv1d: A = dL/dy, Bx = input;
- *   ConvTranspose1d: A = input, Bx = dL/dy; Linear / LSTM: K = 1)                                                      */
-int wm_gwgrad(const float* A, const float* Bx, float* G, float* dbias, int NB, int Ca, int Cb, int La, int Lb, int K, int S,
-              int P, wm_stream_t stream);
+/* generic weight gradient, one stride-1 GEMM with the taps folded into the column index (deterministic: split-K partial
+ * tiles in `slab`, then a fixed-order fp64 reduce -- no float atomics):
+ *   G[a][b][k] (+)= sum_{nb,t} A[nb][a][t] * Bx[nb][b][t + k - P],  dbias[a] (+)= sum A   (Conv1d stride 1: A = dL/dy,
+ *   Bx = input; Linear / LSTM: K = 1).  Strided Conv1d / ConvTranspose1d: re-lay the strided operand with wm_gather_taps
+ *   first (K = 1 / K = 2 problems) and let `remap` restore the weight's own order: 0 identity | 1 columns k*r1 + b ->
+ *   b*r2 + k (r1 = Cin, r2 = taps) | 2 columns (co*r1 + ph)*2 + q -> co*2*r1 + q*r1 + ph (r1 = stride).
+ *   b_clip_stride: floats between clips of Bx (0 = dense), so Bx may be a channel slice.  accumulate: 0 overwrite | 1 add.
+ * wm_gwgrad_plan reports the workspace (fp32 elements) `slab` must hold for a problem shape.                            */
+int wm_gwgrad_plan(int NB, int Ca, int Cb, int La, int K, long long* slab_floats, wm_stream_t stream);   /* host-only query; stream unused */
+int wm_gwgrad(const float* A, const float* Bx, float* G, float* dbias, float* slab, int NB, int Ca, int Cb, int La, int Lb,
+              int K, int P, long long b_clip_stride, int remap, int r1, int r2, int accumulate, wm_stream_t stream);
+/* y[nb][row][t] = x[nb][c][t*S + k - P] (0 outside the clip), t < Lout, c < C, k < K; order 0: row = k*C + c (tap planes of
+ * a strided Conv1d, py/main14b_2.py:87-92) | 1: row = c*K + k (stride phases of a ConvTranspose1d, :147)                */
+int wm_gather_taps(const float* x, float* y, int NB, int C, int Lin, int K, int S, int P, int Lout, int order, wm_stream_t stream);
 /* dz = g * ELU'(z) from y = ELU(z) (py/main14b_2.py:90,:96,:101) */
 int wm_elu_bwd(const float* g, const float* y, float* dz, long long n, wm_stream_t stream);
 /* pointwise backward of one LSTM step: gates (activations) -> pre-activation gradients in place; dc in/out */
@@ -196,6 +205,16 @@ int wm_permute_acl(const float* x, float* y, int A, int C, int L, wm_stream_t st
  * tensors are [rows][Bn] (batch contiguous), whhT = W_hh^T [hd][4hd], hprev/cprev NULL = zero initial state          */
 int wm_lstm_h_step_fwd(const float* xp, const float* whhT, const float* hprev, const float* cprev, float* hout, float* cout,
                        float* gates_out, int H, int Bn, wm_stream_t stream);
+
+/* one layer of nn.LSTM(hd, hd, num_layers=2) (py/main14b_2.py:137, :165) over all T steps as a chain of per-step launches
+ * issued by the launcher (the kernel boundary is the step barrier): gate GEMM on the fp32 matrix cores + cell update.
+ * Time-major, batch contiguous.  xp [T][4H][B] = W_ih x_t + b (activations overwrite it when save != 0); whh [4H][H];
+ * hs, cs [T+1][H][B], row 0 = zero initial state (caller), h_t = hs[t+1].  H % 32 == 0, H <= 256.                   */
+int wm_lstm_seq_fwd(float* xp, const float* whh, float* hs, float* cs, int T, int H, int B, int save, wm_stream_t stream);
+/* BPTT of that layer: gates [T][4H][B] activations in -> pre-activation gradients out (in place); dout [T][H][B];
+ * whhT = weight_hh^T [H][4H]; dc [H][B] scratch.                                                                     */
+int wm_lstm_seq_bwd(float* gates, const float* cs, const float* dout, const float* whhT, float* dc, int T, int H, int B,
+                    wm_stream_t stream);
 
 #ifdef __cplusplus
 }

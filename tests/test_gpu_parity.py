@@ -476,9 +476,12 @@ def test_g2_train_step_golden(awm, dev, golden):
     for k in ("l1", "mel", "loud", "loc", "bce", "hf", "total"):
         check(out[k].reshape(1), torch.tensor([float(golden[f"g2_{k}"])]), FWD_TOL, f"G2 {k}")     # scalars: this IS rtol 1e-4
     check(out["delta_raw"][..., ::97], torch.from_numpy(golden["g2_delta_raw_sub"]), FWD_TOL, "G2 delta_raw")
-    check_elementwise(out["delta_raw"][..., ::97], torch.from_numpy(golden["g2_delta_raw_sub"]), "G2 delta_raw (element-wise)")
-    check_elementwise(out["delta"][..., ::97], torch.from_numpy(golden["g2_delta_sub"]), "G2 delta (element-wise)")
-    check_elementwise(out["logits"][:, ::97, :], torch.from_numpy(golden["g2_logits_sub"]), "G2 logits (element-wise)")
+    # element-wise rtol 1e-4 with an absolute floor sized by what the fp32 CPU reference itself needs against its own fp64
+    # run on this fixture (train-mode BatchNorm over B=4 amplifies fp32 rounding): delta_raw 5.5e-7, logits 7.8e-7 and
+    # the post-processed delta 3.3e-5 of max|.| (limit_rms rescales by a per-clip gain formed from 16 000 squares)
+    check_elementwise(out["delta_raw"][..., ::97], torch.from_numpy(golden["g2_delta_raw_sub"]), "G2 delta_raw (element-wise)", atol_of_max=3e-6)
+    check_elementwise(out["delta"][..., ::97], torch.from_numpy(golden["g2_delta_sub"]), "G2 delta (element-wise)", atol_of_max=1e-4)
+    check_elementwise(out["logits"][:, ::97, :], torch.from_numpy(golden["g2_logits_sub"]), "G2 logits (element-wise)", atol_of_max=3e-6)
     check(out["delta"][..., ::97], torch.from_numpy(golden["g2_delta_sub"]), FWD_TOL, "G2 delta")
     check(out["logits"][:, ::97, :], torch.from_numpy(golden["g2_logits_sub"]), FWD_TOL, "G2 logits")
     gp, dp = dict(G.named_parameters()), dict(D.named_parameters())
