@@ -10,6 +10,7 @@
 //     versa); the packing itself is pure data movement done by the host mirror.
 // Epilogue: + bias[channel] + vec[nb][channel] (message embedding) + residual, then optional ELU (alpha = 1).
 #include "wm_common.hpp"
+#include <type_traits>
 using namespace wm;
 
 namespace {
@@ -25,7 +26,7 @@ struct GConvArgs {
     int st;              // 1: plain (Cout == Mtot, t' = n); >1: pixel shuffle, row m = co*st + phase
     int shp;             // padding of the transposed convolution (t' = n*st + phase - shp)
     int Cout, Lout;
-    int act;             // 0 none, 1 ELU
+    int act;             // 0 none | 1 ELU | 2 multiply by ELU'(aux): aux = `res` holds y = ELU(z) of the tensor the result is a gradient of
     int CI;              // input channels per LDS chunk (even; CI*K <= KR_MAX; CI*XW <= 256*XR)
     int XW;              // input span of one N tile: (BN-1)*S + K
 };
@@ -39,6 +40,20 @@ __device__ __forceinline__ float elu1(float v) {
     const float e = __expf(v) - 1.f;
     const float n = v > -0.35f ? p : e;
     return v > 0.f ? v : n;
+}
+
+typedef __amdgpu_buffer_rsrc_t wm_srd_t;   // 128-bit buffer resource descriptor (kept in scalar registers)
+
+// buffer descriptor over [p, p + bytes): 32-bit per-lane byte offsets + a scalar offset, reads past the end return 0
+__device__ __forceinline__ wm_srd_t make_srd(const float* p, size_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), (short)0, (int)(bytes > 0xfffff000ull ? 0xfffff000ull : bytes),
+                                             0x00020000);
+}
+__device__ __forceinline__ float buf_load(wm_srd_t srd, unsigned voff_bytes, unsigned soff_bytes) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd, (int)voff_bytes, (int)soff_bytes, 0));
+}
+__device__ __forceinline__ void buf_store(wm_srd_t srd, float v, unsigned voff_bytes, unsigned soff_bytes) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), srd, (int)voff_bytes, (int)soff_bytes, 0);
 }
 
 // Implicit-GEMM tile kernel.  Workgroup = 4 waves as MW x (4/MW); a wave owns WM x WN blocks of 32 x 32 (fp32 MFMA
@@ -211,59 +226,75 @@ __global__ __launch_bounds__(256) void gconv2_kernel(GConvArgs a) {
         __syncthreads();
     }
 
-    // ---- epilogue: + bias + per-clip vector + residual, ELU, (pixel-shuffled) store
-    const unsigned obase = (unsigned)nb * (unsigned)a.Cout;               // output row index base (rows of Lout floats)
-    float* __restrict__ yb = a.y;
-    const float* __restrict__ rsb = a.res;
-    if (a.st == 1) {
+    // ---- epilogue: + bias + per-clip vector + residual, ELU, (pixel-shuffled) store.  Addresses are 32-bit offsets into
+    // this clip's output rows (buffer stores: per-lane offset + a wave-uniform row offset), so a stored element costs its
+    // arithmetic only; tiles that lie inside the output skip every bound check.
+    const size_t clip = (size_t)nb * a.Cout * a.Lout;
+    const wm_srd_t sy = make_srd(a.y + clip, (size_t)a.Cout * a.Lout * sizeof(float));
+    const wm_srd_t sr = make_srd(a.res ? a.res + clip : a.y + clip, (size_t)a.Cout * a.Lout * sizeof(float));
+    const bool has_res = a.res != nullptr && a.act != 2, act = a.act == 1, mul_dact = a.act == 2 && a.res != nullptr;
+    const float* vecb = a.vec ? a.vec + (size_t)nb * a.Cout : nullptr;
+    // per 32-row block: (1) + bias (+ per-clip vector), (2) all residual loads issued together, one wait, (3) ELU, (4) stores --
+    // the optional stages are wave-uniform branches around straight-line code, never a branch per element
+    const unsigned inv = (65536u + (unsigned)a.st - 1u) / (unsigned)a.st;       // exact m / st for m < 8192, st <= 8
+    const bool shuffle = a.st > 1;
+    int ncol[WN];                                                               // output position index n of this lane
 #pragma unroll
-        for (int i = 0; i < WM; ++i) {
-            const int mrow0 = m0 + (wm_ * WM + i) * 32 + 4 * half;
+    for (int j = 0; j < WN; ++j) ncol[j] = n0 + (wn * WN + j) * 32 + l31;
+    const int tlo = n0 * a.st - a.shp, thi = (n0 + BN - 1) * a.st + a.st - 1 - a.shp;
+    const bool inner = (m0 + BM <= a.Mtot) && (n0 + BN <= a.Nout) && (!shuffle || (tlo >= 0 && thi < a.Lout));
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = mrow0 + (r & 3) + 8 * (r >> 2);
-                if (m >= a.Mtot) continue;
-                float add = a.bias ? a.bias[m] : 0.f;
-                if (a.vec) add += a.vec[obase + m];
-                const size_t rowoff = (size_t)(obase + m) * a.Lout;
+    for (int i = 0; i < WM; ++i) {
+        unsigned off[16][WN];                                                   // byte offset inside the clip, 0xffffffff = no store
 #pragma unroll
-                for (int j = 0; j < WN; ++j) {
-                    const int n = n0 + (wn * WN + j) * 32 + l31;
-                    if (n < a.Nout) {
-                        float v = acc[i][j][r] + add;
-                        if (rsb) v += rsb[rowoff + n];
-                        if (a.act == 1) v = elu1(v);
-                        yb[rowoff + n] = v;
-                    }
-                }
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + (wm_ * WM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            const int mc = min(m, a.Mtot - 1);
+            int co = mc, ph = 0;
+            if (shuffle) { co = (int)(((unsigned)mc * inv) >> 16); ph = mc - co * a.st; }
+            float add = a.bias ? a.bias[co] : 0.f;
+            if (vecb) add += vecb[co];
+            const int rowv = co * a.Lout + ph - (shuffle ? a.shp : 0);
+#pragma unroll
+            for (int j = 0; j < WN; ++j) {
+                const int t = shuffle ? ncol[j] * a.st + ph - a.shp : ncol[j];
+                const bool ok = inner || (m < a.Mtot && ncol[j] < a.Nout && t >= 0 && t < a.Lout);
+                off[r][j] = ok ? (unsigned)(rowv + (shuffle ? ncol[j] * a.st : ncol[j])) * 4u : 0xffffffffu;
+                acc[i][j][r] += add;
             }
         }
-    } else {
-        const unsigned inv = (65536u + (unsigned)a.st - 1u) / (unsigned)a.st;   // exact m / st for m < 8192, st <= 8
+        if (has_res) {
+            float rv[16][WN];
 #pragma unroll
-        for (int i = 0; i < WM; ++i) {
-            const int mrow0 = m0 + (wm_ * WM + i) * 32 + 4 * half;
+            for (int r = 0; r < 16; ++r)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = mrow0 + (r & 3) + 8 * (r >> 2);
-                if (m >= a.Mtot) continue;
-                const int co = (int)(((unsigned)m * inv) >> 16), ph = m - co * a.st;
-                float add = a.bias ? a.bias[co] : 0.f;
-                if (a.vec) add += a.vec[obase + co];
-                const size_t rowoff = (size_t)(obase + co) * a.Lout;
+                for (int j = 0; j < WN; ++j) rv[r][j] = buf_load(sr, off[r][j], 0u);    // 0xffffffff is out of range: reads 0
 #pragma unroll
-                for (int j = 0; j < WN; ++j) {
-                    const int n = n0 + (wn * WN + j) * 32 + l31;
-                    const int t = n * a.st + ph - a.shp;
-                    if (n < a.Nout && t >= 0 && t < a.Lout) {
-                        float v = acc[i][j][r] + add;
-                        if (rsb) v += rsb[rowoff + t];
-                        if (a.act == 1) v = elu1(v);
-                        yb[rowoff + t] = v;
-                    }
-                }
-            }
+            for (int r = 0; r < 16; ++r)
+#pragma unroll
+                for (int j = 0; j < WN; ++j) acc[i][j][r] += rv[r][j];
         }
+        if (act) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+#pragma unroll
+                for (int j = 0; j < WN; ++j) acc[i][j][r] = elu1(acc[i][j][r]);
+        }
+        if (mul_dact) {                                                         // dz = g * ELU'(z), ELU'(z) = 1 (y > 0) | y + 1
+            float yv[16][WN];
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+#pragma unroll
+                for (int j = 0; j < WN; ++j) yv[r][j] = buf_load(sr, off[r][j], 0u);
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+#pragma unroll
+                for (int j = 0; j < WN; ++j) acc[i][j][r] *= (yv[r][j] > 0.f ? 1.f : yv[r][j] + 1.f);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+#pragma unroll
+            for (int j = 0; j < WN; ++j) buf_store(sy, acc[i][j][r], off[r][j], 0u);    // out-of-range offsets are dropped by the hardware
     }
 }
 
@@ -398,18 +429,7 @@ struct GWArgs {
 constexpr int GW_RA = 16;   // A staging units per wave and chunk (unit = one wave-wide dword load)
 constexpr int GW_RB = 36;   // Bx staging units per wave and chunk
 
-typedef __amdgpu_buffer_rsrc_t wm_srd_t;   // 128-bit buffer resource descriptor (kept in scalar registers)
-
-// buffer descriptor over [p, p + bytes): 32-bit per-lane byte offsets + a scalar offset, reads past the end return 0
-__device__ __forceinline__ wm_srd_t make_srd(const float* p, size_t bytes) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), (short)0, (int)(bytes > 0xfffff000ull ? 0xfffff000ull : bytes),
-                                             0x00020000);
-}
-__device__ __forceinline__ float buf_load(wm_srd_t srd, unsigned voff_bytes, unsigned soff_bytes) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd, (int)voff_bytes, (int)soff_bytes, 0));
-}
-
-template <int WA, int NS>
+template <int WA, int NS, bool GEO1>   // GEO1: one 64-position block per staged row (ncb == 1, rows wider than 32): no unit decode
 __global__ __launch_bounds__(256) void gwgrad2_kernel(GWArgs g) {
     constexpr int TA = 32 * WA;
     extern __shared__ __align__(16) float smem[];
@@ -419,10 +439,10 @@ __global__ __launch_bounds__(256) void gwgrad2_kernel(GWArgs g) {
     const int ta = blockIdx.x / g.ntj, tj = blockIdx.x - ta * g.ntj;
     const int TJ = g.WJW * 32 * g.nsub;
     const int a0 = ta * TA, j0 = tj * TJ, b0 = j0 / g.K;
-    const int TC = g.TC, BW = TC + g.K - 1, ncb = g.ncb;
+    const int TC = g.TC, BW = TC + g.K - 1, ncb = GEO1 ? 1 : g.ncb;
     // staging geometry (wave-uniform).  A unit is one wave-wide dword load: 64 positions of one row, or (rows <= 32 wide)
     // 32 positions of two rows.  Only rows that exist are staged; LDS rows are padded to whole units (no store predicate).
-    const int rpu = BW <= 32 ? 2 : 1;                       // rows per unit, A and Bx alike (BW >= TC)
+    const int rpu = GEO1 ? 1 : (BW <= 32 ? 2 : 1);          // rows per unit, A and Bx alike (BW >= TC)
     const int a_rows = min(TA, g.Ca - a0), b_rows = min(g.NBCH, g.Cb - b0);
     const int a_units = ((a_rows + rpu - 1) / rpu) * ncb, b_units = ((b_rows + rpu - 1) / rpu) * ncb;
     const int row_l = rpu == 2 ? half : 0, col_l = rpu == 2 ? l31 : lane;
@@ -468,7 +488,7 @@ __global__ __launch_bounds__(256) void gwgrad2_kernel(GWArgs g) {
             for (int i = 0; i < GW_RA; ++i) {
                 const int u = wv + 4 * i;
                 if (u < a_units) {
-                    const int rg = (int)(((unsigned)u * inv_ncb) >> 16), cb = u - rg * ncb;
+                    const int rg = GEO1 ? u : (int)(((unsigned)u * inv_ncb) >> 16), cb = GEO1 ? 0 : u - rg * ncb;
                     ra[i] = buf_load(sa, vA * 4u, (unsigned)((a0 + rg * rpu) * g.La + t0 + cb * 64) * 4u);
                 }
             }
@@ -476,7 +496,7 @@ __global__ __launch_bounds__(256) void gwgrad2_kernel(GWArgs g) {
             for (int i = 0; i < GW_RB; ++i) {
                 const int u = wv + 4 * i;
                 if (u < b_units) {
-                    const int rg = (int)(((unsigned)u * inv_ncb) >> 16), cb = u - rg * ncb;
+                    const int rg = GEO1 ? u : (int)(((unsigned)u * inv_ncb) >> 16), cb = GEO1 ? 0 : u - rg * ncb;
                     rb[i] = buf_load(sb, vB * 4u, (unsigned)((b0 + rg * rpu) * g.Lb + u0 + cb * 64) * 4u);
                 }
             }
@@ -485,7 +505,7 @@ __global__ __launch_bounds__(256) void gwgrad2_kernel(GWArgs g) {
             for (int i = 0; i < GW_RA; ++i) {
                 const int u = wv + 4 * i;
                 if (u < a_units) {
-                    const int rg = (int)(((unsigned)u * inv_ncb) >> 16), cb = u - rg * ncb;
+                    const int rg = GEO1 ? u : (int)(((unsigned)u * inv_ncb) >> 16), cb = GEO1 ? 0 : u - rg * ncb;
                     const int a = a0 + rg * rpu + row_l, col = cb * 64 + col_l, t = t0 + col;
                     const bool ok = (a < g.Ca) && (col < TC) && (t < g.La);
                     const float v = Ab[(unsigned)(min(a, g.Ca - 1) * g.La + min(t, g.La - 1))];
@@ -496,7 +516,7 @@ __global__ __launch_bounds__(256) void gwgrad2_kernel(GWArgs g) {
             for (int i = 0; i < GW_RB; ++i) {
                 const int u = wv + 4 * i;
                 if (u < b_units) {
-                    const int rg = (int)(((unsigned)u * inv_ncb) >> 16), cb = u - rg * ncb;
+                    const int rg = GEO1 ? u : (int)(((unsigned)u * inv_ncb) >> 16), cb = GEO1 ? 0 : u - rg * ncb;
                     const int b = b0 + rg * rpu + row_l, col = cb * 64 + col_l, uu = u0 + col;
                     const bool ok = (b < g.Cb) && (col < BW) && (uu >= 0) && (uu < g.Lb);
                     const float v = Bb[(unsigned)(min(b, g.Cb - 1) * g.Lb + min(max(uu, 0), g.Lb - 1))];
@@ -512,7 +532,7 @@ __global__ __launch_bounds__(256) void gwgrad2_kernel(GWArgs g) {
         for (int i = 0; i < GW_RA; ++i) {
             const int u = wv + 4 * i;
             if (u < a_units) {
-                const int rg = (int)(((unsigned)u * inv_ncb) >> 16), cb = u - rg * ncb;
+                const int rg = GEO1 ? u : (int)(((unsigned)u * inv_ncb) >> 16), cb = GEO1 ? 0 : u - rg * ncb;
                 (smem + rg * rpu * g.AP + cb * 64)[lA] = ra[i];
             }
         }
@@ -520,7 +540,7 @@ __global__ __launch_bounds__(256) void gwgrad2_kernel(GWArgs g) {
         for (int i = 0; i < GW_RB; ++i) {
             const int u = wv + 4 * i;
             if (u < b_units) {
-                const int rg = (int)(((unsigned)u * inv_ncb) >> 16), cb = u - rg * ncb;
+                const int rg = GEO1 ? u : (int)(((unsigned)u * inv_ncb) >> 16), cb = GEO1 ? 0 : u - rg * ncb;
                 (smem + rg * rpu * g.BP + cb * 64)[lB] = rb[i];
             }
         }
@@ -649,21 +669,29 @@ __global__ __launch_bounds__(256) void gwgrad2_reduce_kernel(const float* __rest
 //            skip convolution reads plane P);  order 1: row = c*K + k (stride phases of a ConvTranspose1d's output gradient)
 __global__ __launch_bounds__(256) void gather_taps_kernel(const float* __restrict__ x, float* __restrict__ y, int C, int Lin, int K,
                                                           int S, int P, int Lout, int order) {
-    const int t = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y, nb = blockIdx.z;
-    if (t >= Lout) return;
+    // one workgroup = 256 output positions of one input row: the span of x they touch is read ONCE, coalesced, into LDS;
+    // every tap plane is then a strided LDS read and a coalesced store
+    __shared__ float xs[255 * 8 + 16 + 8];
+    const int t0 = blockIdx.x * 256, c = blockIdx.y, nb = blockIdx.z, tid = threadIdx.x;
     const float* xr = x + ((size_t)nb * C + c) * Lin;
+    const int u0 = t0 * S - P, span = 255 * S + K;
+    for (int i = tid; i < span; i += 256) {
+        const int u = u0 + i;
+        xs[i] = (u >= 0 && u < Lin) ? xr[u] : 0.f;
+    }
+    __syncthreads();
+    const int t = t0 + tid;
+    if (t >= Lout) return;
     float* yb = y + (size_t)nb * C * K * Lout;
     for (int k = 0; k < K; ++k) {
-        const int u = t * S + k - P;
-        const float v = (u >= 0 && u < Lin) ? xr[u] : 0.f;
         const int row = order ? c * K + k : k * C + c;
-        yb[(size_t)row * Lout + t] = v;
+        yb[(size_t)row * Lout + t] = xs[tid * S + k];
     }
 }
 
-template <int WA, int NS>
+template <int WA, int NS, bool GEO1>
 int launch_gwgrad2(const GWArgs& g, dim3 grid, size_t lds, hipStream_t stream) {
-    auto kern = gwgrad2_kernel<WA, NS>;
+    auto kern = gwgrad2_kernel<WA, NS, GEO1>;
     static wm::DevOnce once;
     if (!wm::dev_done(once)) {
         WM_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
@@ -688,15 +716,21 @@ GWPlan gw_plan(int NB, int Ca, int Cb, int La, int K) {
     const int nsub_total = (NJ + 31) / 32;
     p.WJW = 1;
     while (p.WJW < R && nsub_total > 4 * p.WJW) p.WJW *= 2;
-    p.nsub = (nsub_total + p.WJW - 1) / p.WJW;
-    if (p.nsub > 4) p.nsub = 4;
     p.WT = R / p.WJW;
-    for (;;) {                                              // K = 1: every column is its own channel -- bound the rows staged
-        const int TJ = p.WJW * 32 * p.nsub;
-        p.NBCH = (TJ - 1) / K + 2;
+    // 32-column blocks per wave (<= 4): the count that wastes the fewest matrix-core columns over all column tiles, the
+    // larger on ties; K = 1: every column is its own channel -- at most 128 staged rows
+    int best = 1, best_waste = 1 << 30;
+    for (int ns = 4; ns >= 1; --ns) {
+        const int tjb = p.WJW * ns;                                  // blocks per column tile
+        if (K == 1 && tjb * 32 > 128 && ns > 1) continue;
+        const int waste = ((nsub_total + tjb - 1) / tjb) * tjb - nsub_total;
+        if (waste < best_waste) { best_waste = waste; best = ns; }
+    }
+    p.nsub = best;
+    {
+        const int TJ0 = p.WJW * 32 * p.nsub;
+        p.NBCH = (TJ0 - 1) / K + 2;
         if (p.NBCH > Cb) p.NBCH = Cb;
-        if (p.NBCH <= 128 || p.nsub == 1) break;
-        --p.nsub;
     }
     const int TJ = p.WJW * 32 * p.nsub;
     p.ntj = (NJ + TJ - 1) / TJ;
@@ -726,15 +760,14 @@ GWPlan gw_plan(int NB, int Ca, int Cb, int La, int K) {
             const size_t red = (size_t)(p.WT - 1) * p.WA * p.WJW * 4 * 16 * 64 * sizeof(float);
             if (red > lds) lds = red;
             if (lds < 1024 * sizeof(float)) lds = 1024 * sizeof(float);
-            if (a_units <= 4 * GW_RA && b_units <= 4 * GW_RB && lds <= 50 * 1024) { p.lds = lds; p.ncb = ncb; p.ok = true; }
+            if (a_units <= 4 * GW_RA && b_units <= 4 * GW_RB && lds <= 78 * 1024) { p.lds = lds; p.ncb = ncb; p.ok = true; }   // two workgroups per CU
         }
     }
     if (!p.ok) return p;
     const long long nwork = (long long)NB * p.nchunks;
     const int tiles = p.nta * p.ntj;
-    long long gz = tiles >= 768 ? 1 : 768 / tiles;          // ~768 workgroups = three per CU (what LDS and registers admit)
+    long long gz = tiles >= 512 ? 1 : 512 / tiles;         // <= 512 workgroups = two per CU (what the registers admit): one round
     if (gz > nwork) gz = nwork;
-    if (gz > 256) gz = 256;
     if (gz < 1) gz = 1;
     p.gz = (int)gz;
     p.slab_floats = (size_t)p.gz * Ca * (NJ + 1);           // [gz][Ca][NJ] then [gz][Ca] bias partials
@@ -980,10 +1013,11 @@ int wm_gwgrad(const float* A, const float* Bx, float* G, float* dbias, float* sl
     dim3 grid(p.nta * p.ntj, p.gz);
     const int ns = p.nsub == 1 ? 1 : (p.nsub == 2 ? 2 : 4);
     int rc = 0;
-    if (p.WA == 1) rc = ns == 1 ? launch_gwgrad2<1, 1>(g, grid, p.lds, stream) : ns == 2 ? launch_gwgrad2<1, 2>(g, grid, p.lds, stream)
-                                                                                          : launch_gwgrad2<1, 4>(g, grid, p.lds, stream);
-    else rc = ns == 1 ? launch_gwgrad2<2, 1>(g, grid, p.lds, stream) : ns == 2 ? launch_gwgrad2<2, 2>(g, grid, p.lds, stream)
-                                                                                : launch_gwgrad2<2, 4>(g, grid, p.lds, stream);
+    const bool geo1 = (p.ncb == 1) && (p.TC + K - 1 > 32);
+#define WM_GW(WA_, NS_) (geo1 ? launch_gwgrad2<WA_, NS_, true>(g, grid, p.lds, stream) : launch_gwgrad2<WA_, NS_, false>(g, grid, p.lds, stream))
+    if (p.WA == 1) rc = ns == 1 ? WM_GW(1, 1) : ns == 2 ? WM_GW(1, 2) : WM_GW(1, 4);
+    else rc = ns == 1 ? WM_GW(2, 1) : ns == 2 ? WM_GW(2, 2) : WM_GW(2, 4);
+#undef WM_GW
     if (rc) return rc;
     const size_t n = (size_t)Ca * NJ;
     hipLaunchKernelGGL(gwgrad2_reduce_kernel, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, stream, slab, G, n, p.gz, NJ, accumulate,
@@ -999,7 +1033,7 @@ int wm_gwgrad(const float* A, const float* Bx, float* G, float* dbias, float* sl
 
 // y[nb][row][t] = x[nb][c][t*S + k - P] (0 outside), t < Lout; order 0: row = k*C + c | 1: row = c*K + k   (see gather_taps_kernel)
 int wm_gather_taps(const float* x, float* y, int NB, int C, int Lin, int K, int S, int P, int Lout, int order, hipStream_t stream) {
-    if (NB <= 0 || NB > 65535 || C <= 0 || C > 65535 || Lin <= 0 || K <= 0 || S <= 0 || Lout <= 0) return (int)hipErrorInvalidValue;
+    if (NB <= 0 || NB > 65535 || C <= 0 || C > 65535 || Lin <= 0 || K <= 0 || K > 16 || S <= 0 || S > 8 || Lout <= 0) return (int)hipErrorInvalidValue;
     hipLaunchKernelGGL(gather_taps_kernel, dim3((Lout + 255) / 256, C, NB), dim3(256), 0, stream, x, y, C, Lin, K, S, P, Lout, order);
     WM_CHECK_LAUNCH();
     return 0;

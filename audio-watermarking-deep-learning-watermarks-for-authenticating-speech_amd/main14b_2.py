@@ -40,12 +40,13 @@ def _conv_fwd(x, w, bias, stride, padding, act=0, res=None, vec=None):
     return _gconv_raw(x, wp, bias, K, stride, padding, Cout, Lout, 1, 0, Cout, Lout, act, res, vec)
 
 
-def _conv_dgrad(g, w, stride, padding, Lin):
-    """dL/dx of Conv1d(w [Cout,Cin,K], stride, padding) for dL/dy = g [NB,Cout,Lout]"""
+def _conv_dgrad(g, w, stride, padding, Lin, res=None, act=0):
+    """dL/dx of Conv1d(w [Cout,Cin,K], stride, padding) for dL/dy = g [NB,Cout,Lout]; epilogue: + res (act 0) or, act 2,
+    multiplied by ELU'(res) (res = the ELU output the gradient flows into: the result is dL/dz)"""
     Cout, Cin, K = w.shape
     if stride == 1:
         wp = w.flip(2).permute(0, 2, 1).reshape(Cout * K, Cin).contiguous()             # rows (co, kk): W[co][ci][K-1-kk]
-        return _gconv_raw(g, wp, None, K, 1, K - 1 - padding, Cin, Lin, 1, 0, Cin, Lin)
+        return _gconv_raw(g, wp, None, K, 1, K - 1 - padding, Cin, Lin, 1, 0, Cin, Lin, act, res)
     # strided conv: its data gradient is a transposed conv = Kg-tap conv onto Cin*stride phase rows + pixel shuffle
     Kg = (K + stride - 1) // stride
     wz = torch.zeros(Cout, Cin, Kg * stride, dtype=w.dtype, device=w.device)
@@ -53,7 +54,7 @@ def _conv_dgrad(g, w, stride, padding, Lin):
     # wp[(co*Kg + kk)][ci*stride + phase] = W[co][ci][phase + (Kg-1-kk)*stride]
     wp = wz.reshape(Cout, Cin, Kg, stride).flip(2).permute(0, 2, 1, 3).reshape(Cout * Kg, Cin * stride).contiguous()
     Nout = (Lin - 1 + padding) // stride + 1
-    return _gconv_raw(g, wp, None, Kg, 1, Kg - 1, Cin * stride, Nout, stride, padding, Cin, Lin)
+    return _gconv_raw(g, wp, None, Kg, 1, Kg - 1, Cin * stride, Nout, stride, padding, Cin, Lin, act, res)
 
 
 _PLAN = {}
@@ -253,6 +254,47 @@ def _conv(x, m, act=0, res=None, vec=None):
     return ConvFn.apply(x, m.weight, m.bias, m.stride[0], m.padding[0], act, res, vec)
 
 
+class ResidualBlockFn(torch.autograd.Function):
+    """ResidualBlock.forward, py/main14b_2.py:95-102: elu(conv2(elu(conv1(x))) + skip(x)) as one tape node.  Backward keeps
+    every gradient sum inside a convolution epilogue: conv2's data gradient leaves its kernel already multiplied by
+    ELU'(out1), and the two paths into x (conv1 / skip or identity) are summed by the second launch's `res` input."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, ws, bs, stride):
+        x = ops._chk(x, "input", 3)
+        out1 = _conv_fwd(x, w1, b1, stride, 1, 1)
+        res = _conv_fwd(x, ws, bs, stride, 0) if ws is not None else x
+        y = _conv_fwd(out1, w2, b2, 1, 1, 1, res)
+        ctx.stride = stride
+        ctx.has_skip = ws is not None
+        ctx.save_for_backward(x, out1, y, w1, w2, ws if ws is not None else x.new_empty(0))
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, out1, y, w1, w2, ws = ctx.saved_tensors
+        stride = ctx.stride
+        gz2 = _elu_bwd(gy.contiguous(), y)                                      # dL/d(conv2 + res)
+        dw2, db2 = _conv_wgrad(gz2, out1, w2.shape, 1, 1, True)
+        gz1 = _conv_dgrad(gz2, w2, 1, 1, out1.shape[2], res=out1, act=2)        # dL/d(conv1 output before its ELU)
+        planes = None
+        if stride > 1:                                                          # tap planes of x: shared by conv1 and the skip conv
+            planes = _gather_taps(x, 3, stride, 1, gz1.shape[2], 0)
+        dw1, db1 = _conv_wgrad(gz1, x, w1.shape, stride, 1, True, planes)
+        dws = dbs = None
+        if ctx.has_skip:
+            Cin, Lo = x.shape[1], gz2.shape[2]
+            if stride > 1:                                                      # x[t*stride] is tap plane 1 (padding 1) of conv1's planes
+                dws, dbs = _gwgrad_raw(gz2, planes[:, Cin:2 * Cin], Cin, Lo, 3 * Cin * Lo, ws.shape, 1, 0, True)
+            else:
+                dws, dbs = _conv_wgrad(gz2, x, ws.shape, 1, 0, True)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            via_skip = _conv_dgrad(gz2, ws, stride, 0, x.shape[2]) if ctx.has_skip else gz2
+            dx = _conv_dgrad(gz1, w1, stride, 1, x.shape[2], res=via_skip)
+        return dx, dw1, db1, dw2, db2, dws, dbs, None
+
+
 class ResidualBlock(nn.Module):
     """py/main14b_2.py:86-102"""
 
@@ -266,9 +308,10 @@ class ResidualBlock(nn.Module):
             self.skip_conv = make_conv1d(in_ch, out_ch, kernel_size=1, stride=stride, padding=0)
 
     def forward(self, x):
-        out = _conv(x, self.conv1, act=1)
-        res = _conv(x, self.skip_conv) if self.downsample else x
-        return _conv(out, self.conv2, act=1, res=res)          # elu(conv2(out) + residual)
+        sk = self.skip_conv if self.downsample else None
+        return ResidualBlockFn.apply(x, self.conv1.weight, self.conv1.bias, self.conv2.weight, self.conv2.bias,
+                                     sk.weight if sk is not None else None, sk.bias if sk is not None else None,
+                                     self.conv1.stride[0])
 
 
 def _fit_length(y, T):

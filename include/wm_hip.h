@@ -171,7 +171,8 @@ int wm_adam_step(float* p, const float* g, float* m, float* v, long long n, doub
  * y[nb][co][t'] = act(bias[co] + vec[nb][co] + res[..] + sum_{ci,k} wp[ci*K+k][m] * x[nb][ci][n*S + k - P])
  *   st == 1: m = co, t' = n  (strided Conv1d :87-92, nn.Linear :134, Conv1d k7 :121,:139,:153)
  *   st  > 1: m = co*st + phase, t' = n*st + phase - shp  (ConvTranspose1d(k=2*st, stride st, padding st/2) :147 as a
- *            2-tap convolution + pixel shuffle).  act: 0 none | 1 ELU (:90).  wp is packed by the host mirror.        */
+ *            2-tap convolution + pixel shuffle).  act: 0 none | 1 ELU (:90) | 2 multiply by ELU'(y) with y read from `res` (the
+ *            data gradient of the convolution behind an ELU, py/main14b_2.py:96-97, leaves the kernel as dL/dz).  wp is packed by the host mirror. */
 int wm_gconv(const float* x, const float* wp, const float* bias, const float* vec, const float* res, float* y, int NB,
              int Cin, int Lin, int K, int S, int P, int Mtot, int Nout, int st, int shp, int Cout, int Lout, int act,
              wm_stream_t stream);
