@@ -27,12 +27,13 @@ struct GConvArgs {
     int shp;             // padding of the transposed convolution (t' = n*st + phase - shp)
     int Cout, Lout;
     int act;             // 0 none | 1 ELU | 2 multiply by ELU'(aux): aux = `res` holds y = ELU(z) of the tensor the result is a gradient of
-    int CI;              // input channels per LDS chunk (even; CI*K <= KR_MAX; CI*XW <= 256*XR)
+    int CI;              // input channels per LDS chunk (even; CI*K <= KR_MAX; CI*XW <= 256*xr_of(BN))
     int XW;              // input span of one N tile: (BN-1)*S + K
 };
 
-constexpr int KR_MAX = 48;   // (channel, tap) rows of the weight image per chunk
-constexpr int XR = 16;       // input-tile elements a thread stages per chunk
+// (channel, tap) rows of the weight image per chunk: sized so that three workgroups' double buffers fit the 160 KB of LDS
+constexpr int kr_max_of(int bm) { return bm >= 128 ? 36 : 48; }
+constexpr int xr_of(int bn) { return bn >= 256 ? 16 : 10; }   // input-tile elements a thread stages per chunk, by tile width
 
 // ELU (alpha = 1) with a cheap expm1: Taylor to the 6th order on (-0.35, 0] (error < 4e-7 of the value), exp(v) - 1 below
 __device__ __forceinline__ float elu1(float v) {
@@ -52,6 +53,10 @@ __device__ __forceinline__ wm_srd_t make_srd(const float* p, size_t bytes) {
 __device__ __forceinline__ float buf_load(wm_srd_t srd, unsigned voff_bytes, unsigned soff_bytes) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd, (int)voff_bytes, (int)soff_bytes, 0));
 }
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 buf_load4(wm_srd_t srd, unsigned voff_bytes, unsigned soff_bytes) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd, (int)voff_bytes, (int)soff_bytes, 0));
+}
 __device__ __forceinline__ void buf_store(wm_srd_t srd, float v, unsigned voff_bytes, unsigned soff_bytes) {
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), srd, (int)voff_bytes, (int)soff_bytes, 0);
 }
@@ -64,8 +69,8 @@ __device__ __forceinline__ void buf_store(wm_srd_t srd, float v, unsigned voff_b
 // element's 32-bit offset is formed once, the chunk advances two wave-uniform base pointers, LDS stores are unconditional
 // (the regions are padded to whole 256-thread passes) and zero padding is applied only by the tiles that touch a clip edge.
 template <int MW, int WM, int WN, bool VECW>
-__global__ __launch_bounds__(256) void gconv2_kernel(GConvArgs a) {
-    constexpr int NWN = 4 / MW, BM = MW * WM * 32, BN = NWN * WN * 32;
+__global__ __launch_bounds__(256, 3) void gconv2_kernel(GConvArgs a) {
+    constexpr int NWN = 4 / MW, BM = MW * WM * 32, BN = NWN * WN * 32, XR = xr_of(BN), KR_MAX = kr_max_of(BM);
     constexpr int WPT = VECW ? (KR_MAX * BM / 4 + 255) / 256 : (KR_MAX * BM + 255) / 256;   // weight pieces per thread
     constexpr int WV = VECW ? 4 : 1;
     extern __shared__ __align__(16) float smem[];
@@ -112,20 +117,27 @@ __global__ __launch_bounds__(256) void gconv2_kernel(GConvArgs a) {
     float xr[XR];
     f32x4 wr4[VECW ? WPT : 1];
     float wr1[VECW ? 1 : WPT];
-    const float* xb = a.x + (size_t)nb * a.Cin * a.Lin;      // advanced by CI rows per chunk (wave-uniform)
-    const float* wb = a.wp;                                  // advanced by CI*K rows per chunk
+    // buffer loads: per-lane 32-bit byte offsets (xo / wo, formed once) + a wave-uniform chunk offset; no 64-bit address
+    // registers, no vector-ALU address arithmetic
+    const wm_srd_t sx = make_srd(a.x + (size_t)nb * a.Cin * a.Lin, (size_t)a.Cin * a.Lin * sizeof(float));
+    const wm_srd_t sw = make_srd(a.wp, (size_t)a.Cin * K * a.Mtot * sizeof(float));
+#pragma unroll
+    for (int i = 0; i < XR; ++i) xo[i] *= 4u;
+#pragma unroll
+    for (int i = 0; i < WPT; ++i) wo[i] *= 4u;
 
     auto load_chunk = [&](int c0) {
         const int crem = a.Cin - c0;
+        const unsigned xs0 = (unsigned)(c0 * a.Lin) * 4u, ws0 = (unsigned)(c0 * K * a.Mtot) * 4u;
         if (crem >= CI) {                                    // full chunk: offsets only
 #pragma unroll
             for (int i = 0; i < XR; ++i)
-                if (i < nx) xr[i] = xb[xo[i]];
+                if (i < nx) xr[i] = buf_load(sx, xo[i], xs0);
 #pragma unroll
             for (int i = 0; i < WPT; ++i) {
                 if (i < nwp) {
-                    if (VECW) wr4[i] = *reinterpret_cast<const f32x4*>(wb + wo[i]);
-                    else wr1[i] = wb[wo[i]];
+                    if (VECW) wr4[i] = buf_load4(sw, wo[i], ws0);
+                    else wr1[i] = buf_load(sw, wo[i], ws0);
                 }
             }
         } else {                                             // last chunk of a channel count that CI does not divide
@@ -134,7 +146,7 @@ __global__ __launch_bounds__(256) void gconv2_kernel(GConvArgs a) {
                 if (i < nx) {
                     const int idx = tid + 256 * i;
                     const int ci = min(idx / XW, CI - 1);
-                    const float v = xb[xo[i] - (unsigned)((ci - min(ci, crem - 1)) * a.Lin)];
+                    const float v = buf_load(sx, xo[i] - (unsigned)((ci - min(ci, crem - 1)) * a.Lin) * 4u, xs0);
                     xr[i] = ci < crem ? v : 0.f;
                 }
             }
@@ -146,10 +158,10 @@ __global__ __launch_bounds__(256) void gconv2_kernel(GConvArgs a) {
                     const int ci = 2 * ((r >> 1) / K) + (r & 1);
                     const bool ok = ci < crem;
                     if (VECW) {
-                        const f32x4 v = *reinterpret_cast<const f32x4*>(wb + (ok ? wo[i] : 0u));
+                        const f32x4 v = buf_load4(sw, ok ? wo[i] : 0u, ws0);
                         wr4[i] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
                     } else {
-                        const float v = wb[ok ? wo[i] : 0u];
+                        const float v = buf_load(sw, ok ? wo[i] : 0u, ws0);
                         wr1[i] = ok ? v : 0.f;
                     }
                 }
@@ -160,8 +172,6 @@ __global__ __launch_bounds__(256) void gconv2_kernel(GConvArgs a) {
             for (int i = 0; i < XR; ++i)
                 if (i < nx) xr[i] = ((xz >> i) & 1u) ? 0.f : xr[i];
         }
-        xb += (size_t)CI * a.Lin;
-        wb += (size_t)KR * a.Mtot;
     };
     auto store_chunk = [&](float* buf) {
 #pragma unroll
@@ -245,56 +255,60 @@ __global__ __launch_bounds__(256) void gconv2_kernel(GConvArgs a) {
     const bool inner = (m0 + BM <= a.Mtot) && (n0 + BN <= a.Nout) && (!shuffle || (tlo >= 0 && thi < a.Lout));
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
-        unsigned off[16][WN];                                                   // byte offset inside the clip, 0xffffffff = no store
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = m0 + (wm_ * WM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            const int mc = min(m, a.Mtot - 1);
-            int co = mc, ph = 0;
-            if (shuffle) { co = (int)(((unsigned)mc * inv) >> 16); ph = mc - co * a.st; }
-            float add = a.bias ? a.bias[co] : 0.f;
-            if (vecb) add += vecb[co];
-            const int rowv = co * a.Lout + ph - (shuffle ? a.shp : 0);
+        for (int rh = 0; rh < 16; rh += 8) {                                    // 8 rows at a time: bounds the live offsets / loads
+            unsigned off[8][WN];                                                // byte offset inside the clip, 0xffffffff = no store
 #pragma unroll
-            for (int j = 0; j < WN; ++j) {
-                const int t = shuffle ? ncol[j] * a.st + ph - a.shp : ncol[j];
-                const bool ok = inner || (m < a.Mtot && ncol[j] < a.Nout && t >= 0 && t < a.Lout);
-                off[r][j] = ok ? (unsigned)(rowv + (shuffle ? ncol[j] * a.st : ncol[j])) * 4u : 0xffffffffu;
-                acc[i][j][r] += add;
+            for (int r8 = 0; r8 < 8; ++r8) {
+                const int r = rh + r8;
+                const int m = m0 + (wm_ * WM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int mc = min(m, a.Mtot - 1);
+                int co = mc, ph = 0;
+                if (shuffle) { co = (int)(((unsigned)mc * inv) >> 16); ph = mc - co * a.st; }
+                float add = a.bias ? a.bias[co] : 0.f;
+                if (vecb) add += vecb[co];
+                const int rowv = co * a.Lout + ph - (shuffle ? a.shp : 0);
+#pragma unroll
+                for (int j = 0; j < WN; ++j) {
+                    const int t = shuffle ? ncol[j] * a.st + ph - a.shp : ncol[j];
+                    const bool ok = inner || (m < a.Mtot && ncol[j] < a.Nout && t >= 0 && t < a.Lout);
+                    off[r8][j] = ok ? (unsigned)(rowv + (shuffle ? ncol[j] * a.st : ncol[j])) * 4u : 0xffffffffu;
+                    acc[i][j][r] += add;
+                }
             }
+            if (has_res) {
+                float rv[8][WN];
+#pragma unroll
+                for (int r8 = 0; r8 < 8; ++r8)
+#pragma unroll
+                    for (int j = 0; j < WN; ++j) rv[r8][j] = buf_load(sr, off[r8][j], 0u);    // 0xffffffff is out of range: reads 0
+#pragma unroll
+                for (int r8 = 0; r8 < 8; ++r8)
+#pragma unroll
+                    for (int j = 0; j < WN; ++j) acc[i][j][rh + r8] += rv[r8][j];
+            }
+            if (act) {
+#pragma unroll
+                for (int r8 = 0; r8 < 8; ++r8)
+#pragma unroll
+                    for (int j = 0; j < WN; ++j) acc[i][j][rh + r8] = elu1(acc[i][j][rh + r8]);
+            }
+            if (mul_dact) {                                                     // dz = g * ELU'(z), ELU'(z) = 1 (y > 0) | y + 1
+                float yv[8][WN];
+#pragma unroll
+                for (int r8 = 0; r8 < 8; ++r8)
+#pragma unroll
+                    for (int j = 0; j < WN; ++j) yv[r8][j] = buf_load(sr, off[r8][j], 0u);
+#pragma unroll
+                for (int r8 = 0; r8 < 8; ++r8)
+#pragma unroll
+                    for (int j = 0; j < WN; ++j) acc[i][j][rh + r8] *= (yv[r8][j] > 0.f ? 1.f : yv[r8][j] + 1.f);
+            }
+#pragma unroll
+            for (int r8 = 0; r8 < 8; ++r8)
+#pragma unroll
+                for (int j = 0; j < WN; ++j) buf_store(sy, acc[i][j][rh + r8], off[r8][j], 0u);   // out-of-range offsets are dropped by the hardware
         }
-        if (has_res) {
-            float rv[16][WN];
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-#pragma unroll
-                for (int j = 0; j < WN; ++j) rv[r][j] = buf_load(sr, off[r][j], 0u);    // 0xffffffff is out of range: reads 0
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-#pragma unroll
-                for (int j = 0; j < WN; ++j) acc[i][j][r] += rv[r][j];
-        }
-        if (act) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-#pragma unroll
-                for (int j = 0; j < WN; ++j) acc[i][j][r] = elu1(acc[i][j][r]);
-        }
-        if (mul_dact) {                                                         // dz = g * ELU'(z), ELU'(z) = 1 (y > 0) | y + 1
-            float yv[16][WN];
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-#pragma unroll
-                for (int j = 0; j < WN; ++j) yv[r][j] = buf_load(sr, off[r][j], 0u);
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-#pragma unroll
-                for (int j = 0; j < WN; ++j) acc[i][j][r] *= (yv[r][j] > 0.f ? 1.f : yv[r][j] + 1.f);
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-#pragma unroll
-            for (int j = 0; j < WN; ++j) buf_store(sy, acc[i][j][r], off[r][j], 0u);    // out-of-range offsets are dropped by the hardware
     }
 }
 
@@ -309,7 +323,7 @@ static int pick_ci(int Cin, int lim) {
 
 template <int MW, int WM, int WN, bool VECW>
 int launch_gconv2(GConvArgs a, hipStream_t stream) {
-    constexpr int BM = MW * WM * 32, BN = (4 / MW) * WN * 32, WV = VECW ? 4 : 1;
+    constexpr int BM = MW * WM * 32, BN = (4 / MW) * WN * 32, WV = VECW ? 4 : 1, XR = xr_of(BN), KR_MAX = kr_max_of(BM);
     a.XW = (BN - 1) * a.S + a.K;
     int lim = KR_MAX / a.K;                                 // weight rows per chunk <= KR_MAX
     const int cx = (256 * XR) / a.XW;                       // staged input elements per thread <= XR
@@ -427,10 +441,10 @@ struct GWArgs {
 };
 
 constexpr int GW_RA = 16;   // A staging units per wave and chunk (unit = one wave-wide dword load)
-constexpr int GW_RB = 36;   // Bx staging units per wave and chunk
+constexpr int GW_RB = 24;   // Bx staging units per wave and chunk
 
 template <int WA, int NS, bool GEO1>   // GEO1: one 64-position block per staged row (ncb == 1, rows wider than 32): no unit decode
-__global__ __launch_bounds__(256) void gwgrad2_kernel(GWArgs g) {
+__global__ __launch_bounds__(256, 3) void gwgrad2_kernel(GWArgs g) {
     constexpr int TA = 32 * WA;
     extern __shared__ __align__(16) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
@@ -722,7 +736,8 @@ GWPlan gw_plan(int NB, int Ca, int Cb, int La, int K) {
     int best = 1, best_waste = 1 << 30;
     for (int ns = 4; ns >= 1; --ns) {
         const int tjb = p.WJW * ns;                                  // blocks per column tile
-        if (K == 1 && tjb * 32 > 128 && ns > 1) continue;
+        const int rows = (tjb * 32 - 1) / K + 2;                     // Bx rows such a tile touches
+        if (ns > 1 && (rows < Cb ? rows : Cb) > 4 * GW_RB) continue;  // more rows than the staging registers hold
         const int waste = ((nsub_total + tjb - 1) / tjb) * tjb - nsub_total;
         if (waste < best_waste) { best_waste = waste; best = ns; }
     }
@@ -760,13 +775,13 @@ GWPlan gw_plan(int NB, int Ca, int Cb, int La, int K) {
             const size_t red = (size_t)(p.WT - 1) * p.WA * p.WJW * 4 * 16 * 64 * sizeof(float);
             if (red > lds) lds = red;
             if (lds < 1024 * sizeof(float)) lds = 1024 * sizeof(float);
-            if (a_units <= 4 * GW_RA && b_units <= 4 * GW_RB && lds <= 78 * 1024) { p.lds = lds; p.ncb = ncb; p.ok = true; }   // two workgroups per CU
+            if (a_units <= 4 * GW_RA && b_units <= 4 * GW_RB && lds <= 52 * 1024) { p.lds = lds; p.ncb = ncb; p.ok = true; }   // three workgroups per CU
         }
     }
     if (!p.ok) return p;
     const long long nwork = (long long)NB * p.nchunks;
     const int tiles = p.nta * p.ntj;
-    long long gz = tiles >= 512 ? 1 : 512 / tiles;         // <= 512 workgroups = two per CU (what the registers admit): one round
+    long long gz = tiles >= 768 ? 1 : 768 / tiles;         // <= 768 workgroups = three per CU (registers and LDS admit three): one round
     if (gz > nwork) gz = nwork;
     if (gz < 1) gz = 1;
     p.gz = (int)gz;
