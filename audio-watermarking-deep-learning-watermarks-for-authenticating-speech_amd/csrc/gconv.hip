@@ -816,8 +816,9 @@ __global__ void lstm_h_step_bwd_kernel(float* __restrict__ gates, const float* _
     dc[i] = dct * gf;
 }
 
-// out[c] += sum_{nb,t} x[nb][c][t]      (bias gradient of the transposed convolutions); one block per channel
-__global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restrict__ x, float* __restrict__ out, int NB, int C, int L) {
+// partial[c][y] = sum over clips nb == y (mod gridDim.y) and all t of x[nb][c][t]; channel_sum_final adds the partials of a
+// channel in fixed order (bias gradient of the transposed convolutions; no atomics: bit-reproducible)
+__global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restrict__ x, float* __restrict__ partial, int NB, int C, int L) {
     __shared__ float scratch[4];
     const int c = blockIdx.x;
     float s = 0.f;
@@ -826,7 +827,14 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restric
         for (int t = threadIdx.x; t < L; t += 256) s += r[t];
     }
     s = block_sum<4>(s, scratch);
-    if (threadIdx.x == 0) atomicAdd(out + c, s);
+    if (threadIdx.x == 0) partial[(size_t)c * gridDim.y + blockIdx.y] = s;
+}
+__global__ void channel_sum_final_kernel(const float* __restrict__ partial, float* __restrict__ out, int C, int ny, int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0;
+    for (int y = 0; y < ny; ++y) s += (double)partial[(size_t)c * ny + y];
+    out[c] = (float)((accumulate ? (double)out[c] : 0.0) + s);
 }
 
 // out[row] = sum_t x[row][t] for any row length
@@ -839,16 +847,22 @@ __global__ __launch_bounds__(256) void rowsum_any_kernel(const float* __restrict
     if (threadIdx.x == 0) out[blockIdx.x] = s;
 }
 
-// dtable[idx[b]][:] += dvec[b][:]   (dense embedding gradient for any embedding width)
+// dtable[idx[b]][:] += dvec[b][:]   (dense embedding gradient for any embedding width).  One thread per column walks the
+// batch in order, so duplicate ids add in a fixed order (bit-reproducible; B is ~128, the cost is nil)
 __global__ void rows_scatter_add_kernel(float* __restrict__ dtable, const long long* __restrict__ idx,
                                         const float* __restrict__ dvec, int Bn, int dim, int nrows) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= Bn * dim) return;
-    const long long m = idx[i / dim];
-    if (m < 0 || m >= nrows) return;
-    atomicAdd(dtable + (size_t)m * dim + (i % dim), dvec[i]);
+    const int d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= dim) return;
+    for (int b = 0; b < Bn; ++b) {
+        const long long m = idx[b];
+        if (m < 0 || m >= nrows) continue;
+        dtable[(size_t)m * dim + d] += dvec[(size_t)b * dim + d];
+    }
 }
 
+}  // namespace
+
+namespace {
 
 // ---------------------------------------------------------------------------------------------------------------
 // nn.LSTM(hd, hd, num_layers=2) over the T = 50 latent steps (py/main14b_2.py:137, :165): the recurrence of ONE layer as
@@ -1067,8 +1081,13 @@ int wm_lstm_h_step_bwd(float* gates, const float* c, const float* cprev, const f
     return 0;
 }
 
-int wm_channel_sum(const float* x, float* out, int NB, int C, int L, hipStream_t stream) {
-    hipLaunchKernelGGL(channel_sum_kernel, dim3(C, NB < 64 ? NB : 64), dim3(256), 0, stream, x, out, NB, C, L);
+// out[c] (+)= sum_{nb,t} x[nb][c][t]; partial: >= 64*C floats of scratch.  Fixed summation order (no atomics).
+int wm_channel_sum(const float* x, float* out, float* partial, int NB, int C, int L, int accumulate, hipStream_t stream) {
+    if (NB <= 0 || C <= 0 || L <= 0 || !partial) return (int)hipErrorInvalidValue;
+    const int ny = NB < 64 ? NB : 64;
+    hipLaunchKernelGGL(channel_sum_kernel, dim3(C, ny), dim3(256), 0, stream, x, partial, NB, C, L);
+    WM_CHECK_LAUNCH();
+    hipLaunchKernelGGL(channel_sum_final_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, partial, out, C, ny, accumulate);
     WM_CHECK_LAUNCH();
     return 0;
 }
@@ -1080,7 +1099,7 @@ int wm_rowsum_any(const float* x, float* out, int rows, int L, hipStream_t strea
 }
 
 int wm_rows_scatter_add(float* dtable, const long long* idx, const float* dvec, int Bn, int dim, int nrows, hipStream_t stream) {
-    hipLaunchKernelGGL(rows_scatter_add_kernel, dim3((Bn * dim + 255) / 256), dim3(256), 0, stream, dtable, idx, dvec, Bn, dim, nrows);
+    hipLaunchKernelGGL(rows_scatter_add_kernel, dim3((dim + 255) / 256), dim3(256), 0, stream, dtable, idx, dvec, Bn, dim, nrows);
     WM_CHECK_LAUNCH();
     return 0;
 }

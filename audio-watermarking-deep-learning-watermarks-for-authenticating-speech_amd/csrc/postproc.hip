@@ -119,11 +119,15 @@ __global__ void embed_gather_kernel(const float* __restrict__ table, const long 
 
 __global__ void embed_scatter_add_kernel(float* __restrict__ dtable, const long long* __restrict__ message,
                                          const float* __restrict__ dvec, int B, int nrows) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= B * 64) return;
-    const long long m = message[i >> 6];
-    if (m < 0 || m >= nrows) return;
-    atomicAdd(dtable + (size_t)m * 64 + (i & 63), dvec[i]);
+    // one thread per embedding column walks the batch in order: duplicate message ids add in a fixed order
+    // (bit-reproducible, no float atomics; B x 64 values, the cost is nil)
+    const int d = threadIdx.x;
+    if (d >= 64) return;
+    for (int b = 0; b < B; ++b) {
+        const long long m = message[b];
+        if (m < 0 || m >= nrows) continue;
+        dtable[(size_t)m * 64 + d] += dvec[(size_t)b * 64 + d];
+    }
 }
 
 // out[row] = sum_t x[row, t]
@@ -181,7 +185,7 @@ int wm_embed_gather(const float* table, const long long* message, float* vec, in
 
 // dtable[message[b],:] += dvec[b,:]   (dense embedding gradient; dtable must be pre-zeroed by the caller)
 int wm_embed_scatter_add(float* dtable, const long long* message, const float* dvec, int B, int nrows, hipStream_t stream) {
-    hipLaunchKernelGGL(embed_scatter_add_kernel, dim3((B * 64 + 255) / 256), dim3(256), 0, stream, dtable, message, dvec, B, nrows);
+    hipLaunchKernelGGL(embed_scatter_add_kernel, dim3(1), dim3(64), 0, stream, dtable, message, dvec, B, nrows);
     WM_CHECK_LAUNCH();
     return 0;
 }

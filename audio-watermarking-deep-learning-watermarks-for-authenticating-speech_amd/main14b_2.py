@@ -165,8 +165,8 @@ class ConvTFn(torch.autograd.Function):
         # a K = 2 stride-1 GEMM over Cout*st channels
         gp = _gather_taps(g, st, st, pad, x.shape[2] + 1, 1)
         dw, _ = _gwgrad_raw(x, gp, Cout * st, x.shape[2] + 1, 0, w.shape, 2, 0, False, 2, st, 0)
-        db = torch.zeros(Cout, dtype=torch.float32, device=g.device)
-        lib.wm_channel_sum(_p(g), _p(db), g.shape[0], Cout, g.shape[2], _stream())
+        db = _f32(Cout, device=g.device)
+        lib.wm_channel_sum(_p(g), _p(db), _p(_f32(64 * Cout, device=g.device)), g.shape[0], Cout, g.shape[2], 0, _stream())
         return dx, dw, db, None
 
 

@@ -195,10 +195,11 @@ int wm_elu_bwd(const float* g, const float* y, float* dz, long long n, wm_stream
 /* pointwise backward of one LSTM step: gates (activations) -> pre-activation gradients in place; dc in/out */
 int wm_lstm_h_step_bwd(float* gates, const float* c, const float* cprev, const float* dh, float* dc, int H, int Bn,
                        wm_stream_t stream);
-/* out[c] += sum_{nb,t} x[nb][c][t] (ACCUMULATES) ; out[row] = sum_t x[row][t] for any row length */
-int wm_channel_sum(const float* x, float* out, int NB, int C, int L, wm_stream_t stream);
+/* out[c] (+)= sum_{nb,t} x[nb][c][t] in a fixed order (partial: >= 64*C floats of scratch; accumulate 0 | 1);
+ * out[row] = sum_t x[row][t] for any row length */
+int wm_channel_sum(const float* x, float* out, float* partial, int NB, int C, int L, int accumulate, wm_stream_t stream);
 int wm_rowsum_any(const float* x, float* out, int rows, int L, wm_stream_t stream);
-/* dense embedding gradient for any width: dtable[idx[b]][:] += dvec[b][:] */
+/* dense embedding gradient for any width: dtable[idx[b]][:] += dvec[b][:], duplicate ids added in batch order */
 int wm_rows_scatter_add(float* dtable, const long long* idx, const float* dvec, int Bn, int dim, int nrows, wm_stream_t stream);
 /* [A][C][L] -> [L][C][A]: batch-major <-> time-major sequence layout around nn.LSTM (:137) */
 int wm_permute_acl(const float* x, float* y, int A, int C, int L, wm_stream_t stream);

@@ -146,3 +146,53 @@ def test_main14b2_train_step_vs_oracle(M):
     for name, mod, ref in (("G", G, gsd), ("D", D, dsd)):
         for k, p in mod.named_parameters():
             assert rel(p.grad, ref[k].grad) <= 3e-3, f"{name}.{k}"
+
+
+def test_full_size_properties_b128(M):
+    """BASELINE configs[4] size (B = 128 clips x 16 000 samples, hidden 256), through size-independent properties:
+    (1) clips are independent units (no BatchNorm in this variant): a clip's delta / logits are bit-identical whether it runs
+        alone or inside the batch of 128 (tile / workgroup mapping, split-K grids, LSTM batch tiles leak nothing);
+    (2) the whole train step is bit-reproducible: the weight gradients are split-K slabs reduced in a fixed order (no float
+        atomics anywhere), so two runs from the same state give identical losses and identical updated parameters;
+    (3) permuting the batch permutes delta exactly and leaves every loss term unchanged up to fp32 summation order."""
+    import awm_amd
+    dev = torch.device("cuda:0")
+    B = 128
+    s = O.synthetic_clips(B, seed=123).to(dev)
+    msg = O.synthetic_messages(B, seed=124).to(dev)
+
+    def fresh():
+        torch.manual_seed(42)
+        G, D = M.Generator(hidden_dim=256), M.Detector()
+        return G.to(dev).train(), D.to(dev).train()
+    G, D = fresh()
+    pick = [0, 1, 77, 127]
+    with torch.no_grad():
+        d_all = G(s, msg)
+        lg_all = D(s + d_all)
+        d_few = G(s[pick], msg[pick])
+        lg_few = D(s[pick] + d_few)
+    assert torch.equal(d_all[pick], d_few), float((d_all[pick] - d_few).abs().max())
+    assert torch.equal(lg_all[pick], lg_few), float((lg_all[pick] - lg_few).abs().max())
+    assert torch.isfinite(lg_all).all() and lg_all.shape == (B, 17, 16000)
+    del d_all, lg_all, d_few, lg_few
+    runs = []
+    for _ in range(2):
+        G, D = fresh()
+        opt = awm_amd.FlatAdam([G, D], lr=1e-3)
+        out = M.train_step(G, D, opt, s, msg)
+        torch.cuda.synchronize()
+        runs.append(({k: float(out[k]) for k in ("l1", "mel", "loud", "loc", "bce", "total")}, opt.flat.clone(), opt.grad.clone()))
+        del out, opt
+    assert runs[0][0] == runs[1][0], (runs[0][0], runs[1][0])
+    assert torch.equal(runs[0][2], runs[1][2]), "gradients differ between two identical runs"
+    assert torch.equal(runs[0][1], runs[1][1]), "updated parameters differ between two identical runs"
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(5)).to(dev)
+    G, D = fresh()
+    with torch.no_grad():
+        _, oa = M.forward_losses(G, D, s, msg)
+        _, ob = M.forward_losses(G, D, s[perm], msg[perm])
+    assert torch.equal(ob["delta"], oa["delta"][perm])
+    for k in ("total", "loc", "bce", "l1", "mel", "loud"):
+        a, b = float(oa[k]), float(ob[k])
+        assert abs(a - b) <= 1e-5 * max(abs(a), abs(b), 1e-6) + 1e-7, (k, a, b)
