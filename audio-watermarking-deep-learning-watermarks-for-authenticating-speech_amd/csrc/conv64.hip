@@ -1745,6 +1745,190 @@ __global__ __launch_bounds__(256) void wgrad64bf_kernel(Wgrad64Args a) {
     }
 }
 
+// Output-split build of the same kernel: a wave keeps one 32 x 32 block per tap instead of the whole 64 x 64 x 3 result, so the
+// workgroup needs ~200 registers per lane and can be co-resident with the LSTM recurrence kernels (side-stream overlap).
+template <int GPRO, int XPRO>
+__global__ __launch_bounds__(256) void wgrad64bf_small_kernel(Wgrad64Args a) {
+    constexpr int KW = 3, NT = 128, NP = 3, PG = 136, PX = 152, XO = 8;   // X element index = (t - t0) + XO
+    constexpr int QR = NT / 4, NV = 64 * QR / 256;
+    constexpr bool GTWO = (GPRO == PRO_BNBWD);
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    unsigned short* Gb = reinterpret_cast<unsigned short*>(smem_raw);          // [NP][64][PG]
+    unsigned short* Xb = Gb + NP * 64 * PG;                                    // [NP][64][PX]
+    float* Cs = reinterpret_cast<float*>(Xb + NP * 64 * PX);                   // [5][64]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const int T = a.T;
+    const int tilesPerClip = (T + NT - 1) / NT, ntiles = a.B * tilesPerClip;
+
+    float4 sg[NV], sg2[GTWO ? NV : 1], sx[NV];
+    float hx;
+    float bsum[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) bsum[i] = 0.f;
+
+    // global -> register staging in NV + 1 pieces: the main loop issues one piece per MFMA block (a 64..96-KB burst per
+    // CU backs up the memory pipeline and blocks the wave at issue for thousands of cycles; see conv64bf3_kernel)
+    auto load_piece = [&](int tile, int i) {    // branch-free
+        const int b = tile / tilesPerClip, t0 = (tile - b * tilesPerClip) * NT;
+        const size_t base = (size_t)b * 64 * T;
+        if (i < NV) {
+            const int idx = tid + i * 256, c = idx / QR, q = idx % QR;
+            const int t = min(t0 + 4 * q, T - 4);
+            sg[i] = *reinterpret_cast<const float4*>(a.g + base + (size_t)c * T + t);
+            if (GTWO) sg2[i] = *reinterpret_cast<const float4*>(a.g2 + base + (size_t)c * T + t);
+            sx[i] = *reinterpret_cast<const float4*>(a.x + base + (size_t)c * T + t);
+        } else {
+            const int hc = (tid & 127) >> 1, hh = tid & 1;
+            hx = a.x[base + (size_t)hc * T + min(max(hh ? t0 + NT : t0 - 1, 0), T - 1)];
+        }
+    };
+    auto load_tile = [&](int tile) {
+#pragma unroll
+        for (int i = 0; i <= NV; ++i) load_piece(tile, i);
+    };
+    auto put4 = [&](unsigned short* dst, int stride_p, float v0, float v1, float v2, float v3) {
+        unsigned a0, a1, a2, b0, b1, b2;
+        split3_pair(v0, v1, a0, a1, a2);
+        split3_pair(v2, v3, b0, b1, b2);
+        *reinterpret_cast<uint2*>(dst) = make_uint2(a0, b0);
+        *reinterpret_cast<uint2*>(dst + stride_p) = make_uint2(a1, b1);
+        *reinterpret_cast<uint2*>(dst + 2 * stride_p) = make_uint2(a2, b2);
+    };
+    auto write_tile = [&](int tile) {
+        const int b = tile / tilesPerClip, t0 = (tile - b * tilesPerClip) * NT;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int idx = tid + i * 256, c = idx / QR, q = idx % QR, t = t0 + 4 * q;
+            float4 v = sg[i], u = sx[i];
+            if (GPRO == PRO_BNBWD) {
+                const float ca = Cs[c], cb = Cs[64 + c], cc = Cs[128 + c], cl = Cs[320 + c];
+                const float4 w = sg2[i];
+                v.x = pro_apply<PRO_BNBWD>(v.x, w.x, ca, cb, cc, cl); v.y = pro_apply<PRO_BNBWD>(v.y, w.y, ca, cb, cc, cl);
+                v.z = pro_apply<PRO_BNBWD>(v.z, w.z, ca, cb, cc, cl); v.w = pro_apply<PRO_BNBWD>(v.w, w.w, ca, cb, cc, cl);
+            }
+            if (XPRO != PRO_NONE) {
+                const float ca = (XPRO == PRO_ADDVEC) ? a.xa[b * 64 + c] : Cs[192 + c];
+                const float cb = Cs[256 + c];
+                u.x = pro_apply<XPRO>(u.x, 0.f, ca, cb, 0.f); u.y = pro_apply<XPRO>(u.y, 0.f, ca, cb, 0.f);
+                u.z = pro_apply<XPRO>(u.z, 0.f, ca, cb, 0.f); u.w = pro_apply<XPRO>(u.w, 0.f, ca, cb, 0.f);
+            }
+            if (t >= T) { v = make_float4(0.f, 0.f, 0.f, 0.f); u = v; }
+            bsum[i] += (v.x + v.y) + (v.z + v.w);
+            put4(Gb + c * PG + 4 * q, 64 * PG, v.x, v.y, v.z, v.w);
+            put4(Xb + c * PX + XO + 4 * q, 64 * PX, u.x, u.y, u.z, u.w);
+        }
+        if (tid < 128) {
+            const int hc = tid >> 1, hh = tid & 1, t = hh ? t0 + NT : t0 - 1;
+            float v = hx;
+            if (XPRO != PRO_NONE) {
+                const float ca = (XPRO == PRO_ADDVEC) ? a.xa[b * 64 + hc] : Cs[192 + hc];
+                v = pro_apply<XPRO>(v, 0.f, ca, Cs[256 + hc], 0.f);
+            }
+            if (t < 0 || t >= T) v = 0.f;
+            unsigned p0, p1, p2;
+            split3_pair(v, 0.f, p0, p1, p2);
+            const int o = hc * PX + (hh ? XO + NT : XO - 1);
+            Xb[o] = (unsigned short)p0; Xb[64 * PX + o] = (unsigned short)p1; Xb[2 * 64 * PX + o] = (unsigned short)p2;
+        }
+    };
+
+    int tile = WM_XCD_MAP ? xcd_slot() : (int)blockIdx.x;
+    if (tile < ntiles) load_tile(tile);
+    if (tid < 64) {
+        Cs[tid] = GTWO ? a.ga[tid] : 0.f;
+        Cs[64 + tid] = GTWO ? a.gb[tid] : 0.f;
+        Cs[128 + tid] = GTWO ? a.gc[tid] : 0.f;
+        Cs[192 + tid] = (XPRO == PRO_BNRELU) ? a.xa[tid] : 0.f;
+        Cs[256 + tid] = (XPRO == PRO_BNRELU) ? a.xb[tid] : 0.f;
+        Cs[320 + tid] = GTWO ? a.gb[64 + tid] : 0.f;        // low word of the BatchNorm-backward offset
+    }
+    // the element right of the right halo is read by the funnel shift of the last fragment: keep it defined
+    for (int i = tid; i < NP * 64; i += 256) Xb[i * PX + XO + NT + 1] = 0;
+    __syncthreads();
+    if (tile < ntiles) write_tile(tile);
+    __syncthreads();
+
+    // wave (mt, nt) owns ONE 32 x 32 block of every tap's matrix (48 accumulator registers instead of 192) and walks the whole
+    // 128-step tile: ~200 registers per lane in all, so a workgroup fits beside the 152-register LSTM recurrence waves
+    const int mt = wave & 1, nt = wave >> 1;
+    f32x16 acc[KW];
+#pragma unroll
+    for (int k = 0; k < KW; ++k)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
+
+    while (tile < ntiles) {
+        const int next = tile + gridDim.x;
+        const int nextc = min(next, ntiles - 1);         // clamped: a tile past the end is loaded (valid memory) but never written
+#pragma unroll
+        for (int kb = 0; kb < NT / 16; ++kb) {           // the tile's 8 k-blocks of 16 time steps
+            const int e0 = kb * 16 + 8 * half;
+            bf16x8 A[NP];
+#pragma unroll
+            for (int p = 0; p < NP; ++p) A[p] = *reinterpret_cast<const bf16x8*>(Gb + (p * 64 + mt * 32 + l31) * PG + e0);
+            bf16x8 Bc[NP], Bl[NP], Br[NP];
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                const unsigned short* xr = Xb + (p * 64 + nt * 32 + l31) * PX + XO + e0;
+                const uint4 f = *reinterpret_cast<const uint4*>(xr);
+                const unsigned L = *reinterpret_cast<const unsigned*>(xr - 2), R = *reinterpret_cast<const unsigned*>(xr + 8);
+                const uint4 fl = make_uint4(__builtin_amdgcn_alignbit(f.x, L, 16), __builtin_amdgcn_alignbit(f.y, f.x, 16),
+                                            __builtin_amdgcn_alignbit(f.z, f.y, 16), __builtin_amdgcn_alignbit(f.w, f.z, 16));
+                const uint4 fr = make_uint4(__builtin_amdgcn_alignbit(f.y, f.x, 16), __builtin_amdgcn_alignbit(f.z, f.y, 16),
+                                            __builtin_amdgcn_alignbit(f.w, f.z, 16), __builtin_amdgcn_alignbit(R, f.w, 16));
+                Bc[p] = __builtin_bit_cast(bf16x8, f);
+                Bl[p] = __builtin_bit_cast(bf16x8, fl);
+                Br[p] = __builtin_bit_cast(bf16x8, fr);
+            }
+#define WM_MM6(ACC, BB)                                                                              \
+    ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[1], BB[1], ACC, 0, 0, 0);                         \
+    ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0], BB[2], ACC, 0, 0, 0);                         \
+    ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[2], BB[0], ACC, 0, 0, 0);                         \
+    ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0], BB[1], ACC, 0, 0, 0);                         \
+    ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[1], BB[0], ACC, 0, 0, 0);                         \
+    ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0], BB[0], ACC, 0, 0, 0);
+            WM_MM6(acc[0], Bl)
+            WM_MM6(acc[1], Bc)
+            WM_MM6(acc[2], Br)
+#undef WM_MM6
+            load_piece(nextc, kb);                       // pieces 0..7 ride along the 8 k-blocks
+        }
+        load_piece(nextc, NV);
+        __syncthreads();
+        if (next < ntiles) write_tile(next);
+        __syncthreads();
+        tile = next;
+    }
+
+    float* out = a.partial + (size_t)blockIdx.x * (KW * 4096 + 64);
+#pragma unroll
+    for (int k = 0; k < KW; ++k)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) out[(k * 64 + mt * 32 + mfma_row(r, half)) * 64 + nt * 32 + l31] = acc[k][r];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const float v = half_wave_sum(bsum[i]);
+        if (l31 == 0) out[KW * 4096 + (tid >> 5) + 8 * i] = v;
+    }
+}
+
+template <int GPRO, int XPRO>
+int launch_wgrad64bf_small(const Wgrad64Args& a, int* grid_out, hipStream_t stream) {
+    constexpr size_t lds = (size_t)(3 * 64 * 136 + 3 * 64 * 152) * 2 + 6 * 64 * sizeof(float);
+    static wm::DevOnce attr_done;
+    auto kern = wgrad64bf_small_kernel<GPRO, XPRO>;
+    if (!wm::dev_done(attr_done)) {
+        WM_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        wm::dev_mark(attr_done);
+    }
+    const int ntiles = a.B * ((a.T + 127) / 128);
+    const int grid = ntiles < kNumCU ? ntiles : kNumCU;
+    *grid_out = grid;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, a);
+    WM_CHECK_LAUNCH();
+    return 0;
+}
+
 template <int GPRO, int XPRO>
 int launch_wgrad64bf(const Wgrad64Args& a, int* grid_out, hipStream_t stream) {
     constexpr size_t lds = (size_t)(3 * 64 * 136 + 3 * 64 * 152) * 2 + 6 * 64 * sizeof(float);
@@ -2071,12 +2255,15 @@ int wm_wgrad64_bf(const float* g, const float* g2, const float* ga, const float*
     if (B <= 0 || T <= 0 || (T & 3)) return (int)hipErrorInvalidValue;
     Wgrad64Args a{g, g2, ga, gb, gc, x, xa, xb, partial, B, T};
     int grid = 0, rc = (int)hipErrorInvalidValue;
-    if (gpro == PRO_BNBWD && xpro == PRO_BNRELU) rc = launch_wgrad64bf<PRO_BNBWD, PRO_BNRELU>(a, &grid, stream);
-    else if (gpro == PRO_BNBWD && xpro == PRO_NONE) rc = launch_wgrad64bf<PRO_BNBWD, PRO_NONE>(a, &grid, stream);
+    const bool small = (accumulate & 2) != 0;            // output-split build: ~200 registers, co-resident with the LSTM recurrences
+    if (gpro == PRO_BNBWD && xpro == PRO_BNRELU)
+        rc = small ? launch_wgrad64bf_small<PRO_BNBWD, PRO_BNRELU>(a, &grid, stream) : launch_wgrad64bf<PRO_BNBWD, PRO_BNRELU>(a, &grid, stream);
+    else if (gpro == PRO_BNBWD && xpro == PRO_NONE)
+        rc = small ? launch_wgrad64bf_small<PRO_BNBWD, PRO_NONE>(a, &grid, stream) : launch_wgrad64bf<PRO_BNBWD, PRO_NONE>(a, &grid, stream);
     if (rc) return rc;
     const int n = 3 * 4096 + 64;
     hipLaunchKernelGGL(wgrad64_reduce_kernel, dim3((n + 63) / 64), dim3(256), 0, stream, (const float*)partial, grid, 3, 0, dw,
-                       dbias, accumulate);
+                       dbias, accumulate & 1);
     WM_CHECK_LAUNCH();
     return 0;
 }

@@ -398,6 +398,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_fused_kernel(const float* __rest
 __global__ __launch_bounds__(256) void lstm_bwd_kernel(float* __restrict__ gates, const float* __restrict__ cst,
                                                        const float* __restrict__ dh_out, const float* __restrict__ w_hh,
                                                        int T) {
+    __builtin_amdgcn_s_setprio(3);   // latency-bound recurrence: win issue arbitration against co-resident weight-gradient waves
     constexpr int HS = WM_LSTM_HS_BWD;
     __shared__ __align__(16) float das[4][64];      // wave-private da vectors
     __shared__ __align__(16) float part[2][64][4];  // [buffer][k][wave] partial dh

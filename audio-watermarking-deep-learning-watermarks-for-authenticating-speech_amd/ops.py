@@ -85,7 +85,7 @@ def _single_backward(ctx, what):
 # launched on a second HIP stream and ACCUMULATE straight into that bucket (the Function then returns None for
 # them), so they overlap with the latency-bound LSTM recurrence and the HBM-bound element-wise kernels of the main
 # stream.  optim.FlatAdam.finish_backward() joins the streams before the all-reduce / update.
-_ASYNC = {"on": False, "side": None}
+_ASYNC = {"on": False, "side": None, "deferred": []}
 
 
 def set_async_wgrad(on: bool):
@@ -98,7 +98,27 @@ def side_stream():
     return _ASYNC["side"]
 
 
+def release_deferred_wgrads():
+    """Weight-gradient GEMMs queued so far start now, on the side stream, behind everything the current stream has been
+    given up to this point.  Called right before the LSTM BPTT launch (the 8 ms during which the matrix cores are idle and
+    each CU holds only one 152-register recurrence workgroup) and from join_side_stream()."""
+    pend, _ASYNC["deferred"] = _ASYNC["deferred"], []
+    if not pend:
+        return
+    main, side = torch.cuda.current_stream(), side_stream()
+    ev = torch.cuda.Event()
+    ev.record(main)
+    with torch.cuda.stream(side):
+        side.wait_event(ev)
+        for inputs, fn in pend:
+            for t in inputs:
+                if t is not None:
+                    t.record_stream(side)
+            fn()
+
+
 def join_side_stream():
+    release_deferred_wgrads()
     if _ASYNC["side"] is not None:
         torch.cuda.current_stream().wait_stream(_ASYNC["side"])
 
@@ -110,17 +130,15 @@ def _gdst(*params):
     return tuple(getattr(p, "_wm_grad", None) for p in params)
 
 
-def _on_side(inputs, fn):
-    """run fn() (kernel launches) on the side stream after everything enqueued so far on the current stream"""
-    main, side = torch.cuda.current_stream(), side_stream()
-    ev = torch.cuda.Event()
-    ev.record(main)
-    with torch.cuda.stream(side):
-        side.wait_event(ev)
-        for t in inputs:
-            if t is not None:
-                t.record_stream(side)
-        fn()
+def _on_side(inputs, fn, defer=True):
+    """queue fn() (kernel launches) for the side stream.  defer=True: held back until release_deferred_wgrads() -- launched
+    at once they would only take turns with the main stream's convolutions (both want whole CUs); released at the start of
+    the LSTM BPTT they fill the CUs' idle matrix cores instead."""
+    if defer:
+        _ASYNC["deferred"].append((inputs, fn))
+        return
+    _ASYNC["deferred"].append((inputs, fn))
+    release_deferred_wgrads()
 
 
 # ---------------------------------------------------------------------------------------------- conv arithmetic mode
@@ -239,7 +257,7 @@ class ResBlockFn(GradAwareFunction):
             wpart = _f32(2 * NCU * (3 * 4096 + 64), device=dev)
             if _CONV["bf16x6"]:
                 lib.wm_wgrad64_bf(_p(dz2), _p(y2), _p(k2[0]), _p(k2[1]), _p(k2[3]), _p(y1), _p(sc1), _p(sh1), _p(wpart),
-                                  _p(gw2 if side else dw2), _p(gb2 if side else db2), B, T, 3, 1, 1 if side else 0, _stream())
+                                  _p(gw2 if side else dw2), _p(gb2 if side else db2), B, T, 3, 1, 3 if side else 0, _stream())
             else:
                 lib.wm_wgrad64(_p(dz2), _p(y2), _p(k2[0]), _p(k2[1]), _p(k2[3]), _p(y1), _p(sc1), _p(sh1), _p(wpart),
                                _p(gw2 if side else dw2), _p(gb2 if side else db2), B, T, 3, 3, 1, 0, 1 if side else 0, _stream())
@@ -258,7 +276,7 @@ class ResBlockFn(GradAwareFunction):
             wpart = _f32(2 * NCU * (3 * 4096 + 64), device=dev)
             if _CONV["bf16x6"]:
                 lib.wm_wgrad64_bf(_p(dz1), _p(y1), _p(k1[0]), _p(k1[1]), _p(k1[3]), _p(x), None, None, _p(wpart),
-                                  _p(gw1 if side else dw1), _p(gb1 if side else db1), B, T, 3, 0, 1 if side else 0, _stream())
+                                  _p(gw1 if side else dw1), _p(gb1 if side else db1), B, T, 3, 0, 3 if side else 0, _stream())
             else:
                 lib.wm_wgrad64(_p(dz1), _p(y1), _p(k1[0]), _p(k1[1]), _p(k1[3]), _p(x), None, None, _p(wpart),
                                _p(gw1 if side else dw1), _p(gb1 if side else db1), B, T, 3, 3, 0, 0, 1 if side else 0, _stream())
@@ -395,6 +413,7 @@ class LSTMFn(GradAwareFunction):
         B, _, T = x.shape
         dev, st = x.device, _stream()
         dx = torch.empty_like(x)
+        release_deferred_wgrads()                  # side stream: the queued weight-gradient GEMMs run beside the recurrence
         if _LSTM_BWD_FUSED:                        # measured: no faster than the two launches; off by default
             lib.wm_lstm_bwd_fused(_p(gates), _p(cst), _p(dh), _p(w_hh), _p(w_ih), _p(dx), B, T, st)   # gates now holds da
         else:

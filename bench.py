@@ -167,7 +167,8 @@ def build_workload(model, mode, batch, rank, world, dev, torch_adam=False, force
             if world > 1:
                 sync = lambda: wmd.allreduce_gradients(list(G.parameters()) + list(D.parameters()))   # noqa: E731
         else:
-            opt = awm_amd.FlatAdam([G, D], lr=1e-3)
+            # WM_OVERLAP_WGRAD=1: weight-gradient GEMMs on a side stream (co-resident with the LSTM recurrences), A/B knob
+            opt = awm_amd.FlatAdam([G, D], lr=1e-3, overlap_wgrad=os.environ.get("WM_OVERLAP_WGRAD") == "1")
             gsync = wmd.GradSync(opt, early_modules=[D], force=force_sync)
             sync = gsync if (world > 1 or force_sync) else None
     s, msg = synthetic_batch(batch, rank, dev)

@@ -74,7 +74,9 @@ int wm_conv64_bf7(const float* x, const void* wpb, const float* vec, const float
 int wm_wgrad64_bf7(const float* g, const float* x, const float* vec, float* partial, float* dw, float* dbias, int B, int T,
                    int xpro, int accumulate, wm_stream_t stream);
 
-/* bf16x6 build of the k3 Conv1d weight gradient (contract of wm_wgrad64 with KW = 3, layout 0) */
+/* bf16x6 build of the k3 Conv1d weight gradient (contract of wm_wgrad64 with KW = 3, layout 0).  accumulate: bit 0 = add to
+ * dw / dbias, bit 1 = the output-split build (a wave keeps one 32x32 block per tap: ~200 registers per lane, so the workgroup
+ * can share a CU with the LSTM recurrence kernels when it is launched on a side stream; same results)                     */
 int wm_wgrad64_bf(const float* g, const float* g2, const float* ga, const float* gb, const float* gc,
                   const float* x, const float* xa, const float* xb, float* partial, float* dw, float* dbias,
                   int B, int T, int gpro, int xpro, int accumulate, wm_stream_t stream);
