@@ -25,6 +25,7 @@ def collect(d, counter):
 
 def main():
     fdir, wdir, out = sys.argv[1:4]
+    what = sys.argv[4] if len(sys.argv) > 4 else "python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline (B=256, 1xMI355X)"
     fetch, write = collect(fdir, "FETCH_SIZE"), collect(wdir, "WRITE_SIZE")
     kernels = {}
     for k in sorted(set(fetch) | set(write)):
@@ -33,10 +34,12 @@ def main():
         kernels[k] = {"dispatches": len(fetch.get(k, [])) or len(write.get(k, [])),
                       "fetch_KiB_raw_mean": round(fr, 1), "write_KiB_mean": round(wr, 1),
                       "hbm_bytes_per_launch_corrected": int((2.0 * fr + wr) * 1024)}
-    note = ("rocprofv3 --kernel-trace --pmc FETCH_SIZE and (separate pass) --pmc WRITE_SIZE over `python3 bench.py --steps 2 "
-            "--warmup 1 --no-cpu-baseline` (B=256, 1xMI355X).  KiB per dispatch, mean over the dispatches of a kernel "
-            "(Generator-side launches carry B clips, Detector-side 2B).  FETCH doubled (gfx950 correction), WRITE exact.")
-    json.dump({"note": note, "kernels": kernels}, open(out, "w"), indent=1)
+    note = ("rocprofv3 --kernel-trace --pmc FETCH_SIZE and (separate pass) --pmc WRITE_SIZE over `" + what + "`.  KiB per dispatch, "
+            "mean over the dispatches of a kernel (Generator-side launches carry B clips, Detector-side 2B).  FETCH doubled (gfx950 "
+            "correction), WRITE exact.  bytes_per_step = sum over kernels of dispatches x mean bytes / steps run (3 = 1 warm-up + 2).")
+    steps = 3.0
+    total = sum(v["dispatches"] * v["hbm_bytes_per_launch_corrected"] for v in kernels.values()) / steps
+    json.dump({"note": note, "hbm_bytes_per_step": int(total), "kernels": kernels}, open(out, "w"), indent=1)
     print(f"{len(kernels)} kernels -> {out}")
 
 
