@@ -29,6 +29,9 @@ struct GConvArgs {
     int act;             // 0 none | 1 ELU | 2 multiply by ELU'(aux): aux = `res` holds y = ELU(z) of the tensor the result is a gradient of
     int CI;              // input channels per LDS chunk (even; CI*K <= KR_MAX; CI*XW <= 256*xr_of(BN))
     int XW;              // input span of one N tile: (BN-1)*S + K
+    const float* x2;     // optional second source: input channels >= Cin1 are rows of x2 [NB][Cin - Cin1][Lin] (two gradients
+    int Cin1;            //   contracted by one launch: a strided conv and its 1x1 skip conv); Cin1 % CI == 0
+    int nph;             // phases per output channel when st > 1: row m = co*nph + phase, phase < nph <= st
 };
 
 // (channel, tap) rows of the weight image per chunk: sized so that three workgroups' double buffers fit the 160 KB of LDS
@@ -119,7 +122,9 @@ __global__ __launch_bounds__(256, 3) void gconv2_kernel(GConvArgs a) {
     float wr1[VECW ? 1 : WPT];
     // buffer loads: per-lane 32-bit byte offsets (xo / wo, formed once) + a wave-uniform chunk offset; no 64-bit address
     // registers, no vector-ALU address arithmetic
-    const wm_srd_t sx = make_srd(a.x + (size_t)nb * a.Cin * a.Lin, (size_t)a.Cin * a.Lin * sizeof(float));
+    const int cin1 = a.x2 ? a.Cin1 : a.Cin;
+    const wm_srd_t sx = make_srd(a.x + (size_t)nb * cin1 * a.Lin, (size_t)cin1 * a.Lin * sizeof(float));
+    const wm_srd_t sx2 = make_srd(a.x2 ? a.x2 + (size_t)nb * (a.Cin - cin1) * a.Lin : a.x, (size_t)(a.Cin - cin1) * a.Lin * sizeof(float));
     const wm_srd_t sw = make_srd(a.wp, (size_t)a.Cin * K * a.Mtot * sizeof(float));
 #pragma unroll
     for (int i = 0; i < XR; ++i) xo[i] *= 4u;
@@ -128,11 +133,13 @@ __global__ __launch_bounds__(256, 3) void gconv2_kernel(GConvArgs a) {
 
     auto load_chunk = [&](int c0) {
         const int crem = a.Cin - c0;
-        const unsigned xs0 = (unsigned)(c0 * a.Lin) * 4u, ws0 = (unsigned)(c0 * K * a.Mtot) * 4u;
+        const bool second = c0 >= cin1;                      // wave-uniform: the chunk lies in the second source
+        const wm_srd_t sxc = second ? sx2 : sx;
+        const unsigned xs0 = (unsigned)((c0 - (second ? cin1 : 0)) * a.Lin) * 4u, ws0 = (unsigned)(c0 * K * a.Mtot) * 4u;
         if (crem >= CI) {                                    // full chunk: offsets only
 #pragma unroll
             for (int i = 0; i < XR; ++i)
-                if (i < nx) xr[i] = buf_load(sx, xo[i], xs0);
+                if (i < nx) xr[i] = buf_load(sxc, xo[i], xs0);
 #pragma unroll
             for (int i = 0; i < WPT; ++i) {
                 if (i < nwp) {
@@ -146,7 +153,7 @@ __global__ __launch_bounds__(256, 3) void gconv2_kernel(GConvArgs a) {
                 if (i < nx) {
                     const int idx = tid + 256 * i;
                     const int ci = min(idx / XW, CI - 1);
-                    const float v = buf_load(sx, xo[i] - (unsigned)((ci - min(ci, crem - 1)) * a.Lin) * 4u, xs0);
+                    const float v = buf_load(sxc, xo[i] - (unsigned)((ci - min(ci, crem - 1)) * a.Lin) * 4u, xs0);
                     xr[i] = ci < crem ? v : 0.f;
                 }
             }
@@ -246,7 +253,7 @@ __global__ __launch_bounds__(256, 3) void gconv2_kernel(GConvArgs a) {
     const float* vecb = a.vec ? a.vec + (size_t)nb * a.Cout : nullptr;
     // per 32-row block: (1) + bias (+ per-clip vector), (2) all residual loads issued together, one wait, (3) ELU, (4) stores --
     // the optional stages are wave-uniform branches around straight-line code, never a branch per element
-    const unsigned inv = (65536u + (unsigned)a.st - 1u) / (unsigned)a.st;       // exact m / st for m < 8192, st <= 8
+    const unsigned inv = (65536u + (unsigned)a.nph - 1u) / (unsigned)a.nph;     // exact m / nph for m < 8192, nph <= 8
     const bool shuffle = a.st > 1;
     int ncol[WN];                                                               // output position index n of this lane
 #pragma unroll
@@ -264,7 +271,7 @@ __global__ __launch_bounds__(256, 3) void gconv2_kernel(GConvArgs a) {
                 const int m = m0 + (wm_ * WM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                 const int mc = min(m, a.Mtot - 1);
                 int co = mc, ph = 0;
-                if (shuffle) { co = (int)(((unsigned)mc * inv) >> 16); ph = mc - co * a.st; }
+                if (shuffle) { co = (int)(((unsigned)mc * inv) >> 16); ph = mc - co * a.nph; }
                 float add = a.bias ? a.bias[co] : 0.f;
                 if (vecb) add += vecb[co];
                 const int rowv = co * a.Lout + ph - (shuffle ? a.shp : 0);
@@ -330,6 +337,12 @@ int launch_gconv2(GConvArgs a, hipStream_t stream) {
     if (cx < lim) lim = cx;
     if (lim < 2) return (int)hipErrorInvalidValue;
     a.CI = pick_ci(a.Cin, lim);
+    if (a.x2) {                                             // chunks must not straddle the two sources
+        int c = lim & ~1;
+        while (c >= 2 && (a.Cin1 % c != 0 || a.Cin % c != 0)) c -= 2;
+        if (c < 2) return (int)hipErrorInvalidValue;
+        a.CI = c;
+    }
     const int KR = a.CI * a.K;
     const size_t xreg = (((size_t)a.CI * a.XW + 255) >> 8) * 256, wreg = (((size_t)KR * BM / WV + 255) >> 8) * 256 * WV;
     // + slack: the pipelined pair loop reads up to two pairs past the chunk (four weight rows, two input rows further)
@@ -985,11 +998,13 @@ extern "C" {
 //   st == 1: m = co, t' = n (Cout == Mtot, Lout == Nout);  st > 1: m = co*st + phase, t' = n*st + phase - shp.
 int wm_gconv(const float* x, const float* wp, const float* bias, const float* vec, const float* res, float* y, int NB,
              int Cin, int Lin, int K, int S, int P, int Mtot, int Nout, int st, int shp, int Cout, int Lout, int act,
-             hipStream_t stream) {
-    if (NB <= 0 || Cin <= 0 || K <= 0 || K > 16 || S <= 0 || S > 8 || Mtot <= 0 || Nout <= 0 || st < 1 || Lin <= 0 ||
-        Lin >= (1 << 24) || NB > 65535)
+             const float* x2, int Cin1, int nph, hipStream_t stream) {
+    if (NB <= 0 || Cin <= 0 || K <= 0 || K > 16 || S <= 0 || S > 8 || Mtot <= 0 || Nout <= 0 || st < 1 || st > 8 || Lin <= 0 ||
+        Lin >= (1 << 24) || NB > 65535 || Mtot >= 8192)
         return (int)hipErrorInvalidValue;
-    GConvArgs a{x, wp, bias, vec, res, y, NB, Cin, Lin, K, S, P, Mtot, Nout, st, shp, Cout, Lout, act, 0, 0};
+    if (nph <= 0) nph = st;
+    if (nph > st || (x2 && (Cin1 <= 0 || Cin1 >= Cin))) return (int)hipErrorInvalidValue;
+    GConvArgs a{x, wp, bias, vec, res, y, NB, Cin, Lin, K, S, P, Mtot, Nout, st, shp, Cout, Lout, act, 0, 0, x2, x2 ? Cin1 : Cin, nph};
     const bool vec4 = (Mtot % 4 == 0) && ((reinterpret_cast<uintptr_t>(wp) & 15) == 0);
     // tile shape by problem shape: (rows, columns) = (128,128) | (64,128) | (32,256); short sequences (<= 64): (128,64) | (64,64)
     if (!vec4) {

@@ -25,11 +25,12 @@ STRIDES = [2, 4, 5, 8]                                          # :47
 
 
 # ------------------------------------------------------------------------------------------ raw launches
-def _gconv_raw(x, wp, bias, K, S, P, Mtot, Nout, st, shp, Cout, Lout, act=0, res=None, vec=None):
+def _gconv_raw(x, wp, bias, K, S, P, Mtot, Nout, st, shp, Cout, Lout, act=0, res=None, vec=None, x2=None, nph=0, out=None):
     NB, Cin, Lin = x.shape
-    y = _f32(NB, Cout, Lout, device=x.device)
-    lib.wm_gconv(_p(x), _p(wp), _p(bias), _p(vec), _p(res), _p(y), NB, Cin, Lin, K, S, P, Mtot, Nout, st, shp, Cout, Lout, act,
-                 _stream())
+    y = _f32(NB, Cout, Lout, device=x.device) if out is None else out
+    Cin_tot = Cin + (x2.shape[1] if x2 is not None else 0)
+    lib.wm_gconv(_p(x), _p(wp), _p(bias), _p(vec), _p(res), _p(y), NB, Cin_tot, Lin, K, S, P, Mtot, Nout, st, shp, Cout, Lout, act,
+                 _p(x2), Cin if x2 is not None else 0, nph, _stream())
     return y
 
 
@@ -40,13 +41,13 @@ def _conv_fwd(x, w, bias, stride, padding, act=0, res=None, vec=None):
     return _gconv_raw(x, wp, bias, K, stride, padding, Cout, Lout, 1, 0, Cout, Lout, act, res, vec)
 
 
-def _conv_dgrad(g, w, stride, padding, Lin, res=None, act=0):
+def _conv_dgrad(g, w, stride, padding, Lin, res=None, act=0, out=None):
     """dL/dx of Conv1d(w [Cout,Cin,K], stride, padding) for dL/dy = g [NB,Cout,Lout]; epilogue: + res (act 0) or, act 2,
     multiplied by ELU'(res) (res = the ELU output the gradient flows into: the result is dL/dz)"""
     Cout, Cin, K = w.shape
     if stride == 1:
         wp = w.flip(2).permute(0, 2, 1).reshape(Cout * K, Cin).contiguous()             # rows (co, kk): W[co][ci][K-1-kk]
-        return _gconv_raw(g, wp, None, K, 1, K - 1 - padding, Cin, Lin, 1, 0, Cin, Lin, act, res)
+        return _gconv_raw(g, wp, None, K, 1, K - 1 - padding, Cin, Lin, 1, 0, Cin, Lin, act, res, None, None, 0, out)
     # strided conv: its data gradient is a transposed conv = Kg-tap conv onto Cin*stride phase rows + pixel shuffle
     Kg = (K + stride - 1) // stride
     wz = torch.zeros(Cout, Cin, Kg * stride, dtype=w.dtype, device=w.device)
@@ -57,6 +58,23 @@ def _conv_dgrad(g, w, stride, padding, Lin, res=None, act=0):
     return _gconv_raw(g, wp, None, Kg, 1, Kg - 1, Cin * stride, Nout, stride, padding, Cin, Lin, act, res)
 
 
+def _strided_block_dgrad(gz1, w1, gz2, ws, stride, Lin):
+    """dL/dx of a down-sampling ResidualBlock's two paths in ONE launch: conv1 (k3, stride S >= 3, padding 1) and the 1x1
+    skip conv (stride S) both scatter into x -- dx[ci][t*S + k - 1] = sum_co W1[co][ci][k] gz1[co][t] (+ for k = 1:
+    sum_co Ws[co][ci] gz2[co][t]), every other position is zero.  As a GEMM: rows (ci, k) = 3 phases per channel instead of
+    the S phases of a transposed convolution, contraction over the 2*Cout channels of [gz1; gz2] (second source of wm_gconv)."""
+    Cout, Cin, K = w1.shape
+    wcat = torch.zeros(2 * Cout, Cin, K, dtype=w1.dtype, device=w1.device)      # rows: gz1's channels, then gz2's
+    wcat[:Cout] = w1
+    wcat[Cout:, :, 1] = ws[:, :, 0]                                             # x[t*S] is tap 1 of the padded k3 window
+    wp = wcat.reshape(2 * Cout, Cin * K).contiguous()                           # [(src, co)][ci*K + k]
+    NB, Lo = gz1.shape[0], gz1.shape[2]
+    dx = torch.zeros(NB, Cin, Lin, dtype=torch.float32, device=gz1.device)      # positions no tap reaches stay zero
+    return _gconv_raw(gz1, wp, None, 1, 1, 0, Cin * K, Lo, stride, 1, Cin, Lin, 0, None, None, gz2, K, dx)
+
+
+import os as _os
+_FUSED_STRIDED_DGRAD = _os.environ.get("WM_FUSED_STRIDED_DGRAD", "1") == "1"      # A/B knob
 _PLAN = {}
 
 
@@ -113,11 +131,12 @@ class ConvFn(torch.autograd.Function):
     """Conv1d (+ per-(clip,channel) vector + residual) (+ ELU)  --  py/main14b_2.py:83-102, :121, :134, :139, :153"""
 
     @staticmethod
-    def forward(ctx, x, w, b, stride, padding, act, res, vec):
+    def forward(ctx, x, w, b, stride, padding, act, res, vec, grad_rows=None):
         x = ops._chk(x, "input", 3)
         res = res.contiguous() if res is not None else None
         y = _conv_fwd(x, w, b, stride, padding, act, res, vec)
         ctx.cfg = (stride, padding, act, res is not None, vec is not None)
+        ctx.grad_rows = x.shape[0] if grad_rows is None else max(0, min(int(grad_rows), x.shape[0]))
         ctx.save_for_backward(x, w, y if act else x.new_empty(0))
         return y
 
@@ -127,13 +146,20 @@ class ConvFn(torch.autograd.Function):
         stride, padding, act, has_res, has_vec = ctx.cfg
         gy = gy.contiguous()
         gz = _elu_bwd(gy, y) if act else gy
-        dx = _conv_dgrad(gz, w, stride, padding, x.shape[2]) if ctx.needs_input_grad[0] else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if ctx.grad_rows == x.shape[0] or stride != 1:
+                dx = _conv_dgrad(gz, w, stride, padding, x.shape[2])
+            else:       # only clips [0, grad_rows) need an input gradient (the clean half of [watermarked; clean] is data)
+                dx = torch.zeros_like(x)
+                if ctx.grad_rows > 0:
+                    _conv_dgrad(gz[:ctx.grad_rows], w, 1, padding, x.shape[2], out=dx[:ctx.grad_rows])
         dw, db = _conv_wgrad(gz, x, w.shape, stride, padding, True)
         dvec = None
         if has_vec:
             dvec = _f32(gz.shape[0], gz.shape[1], device=gz.device)
             lib.wm_rowsum_any(_p(gz), _p(dvec), gz.shape[0] * gz.shape[1], gz.shape[2], _stream())
-        return dx, dw, db, None, None, None, (gz if has_res else None), dvec
+        return dx, dw, db, None, None, None, (gz if has_res else None), dvec, None
 
 
 class ConvTFn(torch.autograd.Function):
@@ -195,8 +221,9 @@ class RowsGatherFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, table, idx):
-        if ops._CHECK_INDEX["on"] and bool(((idx < 0) | (idx >= table.shape[0])).any().item()):
-            raise IndexError(f"message id out of range for an embedding table of {table.shape[0]} rows")   # nn.Embedding
+        if ops._CHECK_INDEX["mode"] != "off":                  # nn.Embedding raises IndexError (py/main14b_2.py:160)
+            ops._note_index_error(((idx < 0) | (idx >= table.shape[0])).any().to(torch.int32).reshape(1), table.shape[0])
+            idx = idx.clamp(0, table.shape[0] - 1)              # keep the gather in range whatever the mode reports later
         ctx.save_for_backward(idx)
         ctx.shape = table.shape
         return table.index_select(0, idx).contiguous()          # row gather: data movement only
@@ -250,8 +277,8 @@ def make_conv1d(in_ch, out_ch, kernel_size=3, stride=1, padding=1):
     return nn.Conv1d(in_ch, out_ch, kernel_size, stride=stride, padding=padding)
 
 
-def _conv(x, m, act=0, res=None, vec=None):
-    return ConvFn.apply(x, m.weight, m.bias, m.stride[0], m.padding[0], act, res, vec)
+def _conv(x, m, act=0, res=None, vec=None, grad_rows=None):
+    return ConvFn.apply(x, m.weight, m.bias, m.stride[0], m.padding[0], act, res, vec, grad_rows)
 
 
 class ResidualBlockFn(torch.autograd.Function):
@@ -290,8 +317,11 @@ class ResidualBlockFn(torch.autograd.Function):
                 dws, dbs = _conv_wgrad(gz2, x, ws.shape, 1, 0, True)
         dx = None
         if ctx.needs_input_grad[0]:
-            via_skip = _conv_dgrad(gz2, ws, stride, 0, x.shape[2]) if ctx.has_skip else gz2
-            dx = _conv_dgrad(gz1, w1, stride, 1, x.shape[2], res=via_skip)
+            if ctx.has_skip and stride >= 3 and _FUSED_STRIDED_DGRAD:
+                dx = _strided_block_dgrad(gz1, w1, gz2, ws, stride, x.shape[2])
+            else:
+                via_skip = _conv_dgrad(gz2, ws, stride, 0, x.shape[2]) if ctx.has_skip else gz2
+                dx = _conv_dgrad(gz1, w1, stride, 1, x.shape[2], res=via_skip)
         return dx, dw1, db1, dw2, db2, dws, dbs, None
 
 
@@ -359,7 +389,7 @@ class Generator(nn.Module):
         x = _conv(s, self.init_conv)
         x = self.encoder_blocks(x)                                                   # (B,512,T/320)
         vec = RowsGatherFn.apply(self.E.weight, message.to(torch.int64)) if message is not None else None
-        xt = ConvFn.apply(x, self.proj.weight.unsqueeze(-1), self.proj.bias, 1, 0, 0, None, vec)   # proj + embedding add
+        xt = ConvFn.apply(x, self.proj.weight.unsqueeze(-1), self.proj.bias, 1, 0, 0, None, vec, None)   # proj + embedding add
         seq = PermuteFn.apply(xt)                                                    # [T'][hd][B]
         for l in range(self.lstm.num_layers):
             seq = LSTMLayerFn.apply(seq, getattr(self.lstm, f"weight_ih_l{l}"), getattr(self.lstm, f"weight_hh_l{l}"),
@@ -394,10 +424,12 @@ class Detector(nn.Module):
         self.upsample_blocks = nn.Sequential(*dec_blocks)
         self.final_conv = nn.Conv1d(base_channels, 1 + message_bits, kernel_size=7, stride=1, padding=3)
 
-    def forward(self, x):
+    def forward(self, x, input_grad_rows=None):
+        """`input_grad_rows` (optional, not in the reference): only clips [0, input_grad_rows) get an input gradient -- the
+        train step feeds [watermarked; clean] (py/main14b_2.py:306) and the clean half is data"""
         x = ops._chk(x, "clip batch", 3)
         T = x.shape[-1]
-        y = _conv(x, self.init_conv)
+        y = _conv(x, self.init_conv, grad_rows=input_grad_rows)
         y = self.encoder_blocks(y)
         for i, st in enumerate(reversed(self.strides)):
             ct = self.upsample_blocks[2 * i]
@@ -427,7 +459,7 @@ def forward_losses(generator, detector, s, message):
     from . import losses as L
     delta = generator(s, message)
     s_w = L.clamp_peak(s + delta, 1.0)                                   # torch.clamp(s_w, -1, 1)
-    logits = detector(torch.cat([s_w, s], dim=0))                        # (2B, 1+bits, T)
+    logits = detector(torch.cat([s_w, s], dim=0), input_grad_rows=s.shape[0])   # (2B, 1+bits, T)
     loc, bce = L.detection_losses(logits.permute(0, 2, 1).contiguous(), message)
     l1 = L.l1_to_zero(delta)
     mel = L.MultiScaleMelLoss()(s, s_w)
@@ -441,7 +473,8 @@ def forward_losses(generator, detector, s, message):
 
 def train_step(generator, detector, optimizer, s, message, grad_sync=None):
     optimizer.zero_grad(set_to_none=not hasattr(optimizer, "flat"))
-    total, out = forward_losses(generator, detector, s, message)
+    with ops.index_check_mode("deferred" if ops._CHECK_INDEX["mode"] == "sync" else ops._CHECK_INDEX["mode"]):
+        total, out = forward_losses(generator, detector, s, message)   # a bad message id raises at the next step (no mid-step sync)
     total.backward()
     if hasattr(optimizer, "finish_backward"):
         optimizer.finish_backward()

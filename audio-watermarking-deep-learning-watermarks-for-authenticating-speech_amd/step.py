@@ -38,7 +38,9 @@ def train_step(generator, detector, optimizer, s, message, grad_sync=None):
     """One iteration of train_one_epoch's loop body (:242-278): zero_grad, forward, backward, optimizer step.
     `grad_sync` (optional callable) runs between backward and the update -- the data-parallel all-reduce."""
     optimizer.zero_grad(set_to_none=not hasattr(optimizer, "flat"))
-    total, out = forward_losses(generator, detector, s, message)
+    from . import ops
+    with ops.index_check_mode("deferred" if ops._CHECK_INDEX["mode"] == "sync" else ops._CHECK_INDEX["mode"]):
+        total, out = forward_losses(generator, detector, s, message)   # a bad message id raises at the next step (no mid-step sync)
     total.backward()
     if hasattr(optimizer, "finish_backward"):
         optimizer.finish_backward()

@@ -175,9 +175,12 @@ int wm_adam_step(float* p, const float* g, float* m, float* v, long long n, doub
  *   st  > 1: m = co*st + phase, t' = n*st + phase - shp  (ConvTranspose1d(k=2*st, stride st, padding st/2) :147 as a
  *            2-tap convolution + pixel shuffle).  act: 0 none | 1 ELU (:90) | 2 multiply by ELU'(y) with y read from `res` (the
  *            data gradient of the convolution behind an ELU, py/main14b_2.py:96-97, leaves the kernel as dL/dz).  wp is packed by the host mirror. */
+/* x2 / Cin1 (optional, NULL / 0): input channels >= Cin1 are the rows of a second tensor x2 [NB][Cin - Cin1][Lin] -- two
+ * gradients contracted by one launch (a strided Conv1d and its 1x1 skip conv into the same dL/dx).  nph (0 = st): phases per
+ * output channel when st > 1 (m = co*nph + phase, phase < nph <= st): a strided convolution's data gradient only has K phases. */
 int wm_gconv(const float* x, const float* wp, const float* bias, const float* vec, const float* res, float* y, int NB,
              int Cin, int Lin, int K, int S, int P, int Mtot, int Nout, int st, int shp, int Cout, int Lout, int act,
-             wm_stream_t stream);
+             const float* x2, int Cin1, int nph, wm_stream_t stream);
 /* generic weight gradient, one stride-1 GEMM with the taps folded into the column index (deterministic: split-K partial
  * tiles in `slab`, then a fixed-order fp64 reduce -- no float atomics):
  *   G[a][b][k] (+)= sum_{nb,t} A[nb][a][t] * Bx[nb][b][t + k - P],  dbias[a] (+)= sum A   (Conv1d stride 1: A = dL/dy,

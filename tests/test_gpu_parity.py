@@ -227,6 +227,16 @@ def test_out_of_range_message_raises(awm, dev):
     with pytest.raises(IndexError):
         with torch.no_grad():
             G(s, torch.tensor([-1, 5], device=dev))
+    # deferred mode (what train_step uses: no mid-step sync): the error surfaces at the next lookup or at an explicit check
+    from awm_amd import ops
+    with ops.index_check_mode("deferred"):
+        with torch.no_grad():
+            G(s, torch.tensor([5, 70000], device=dev))          # no raise here
+        with pytest.raises(IndexError, match="deferred"):
+            ops.check_message_ids()
+        with torch.no_grad():
+            G(s, torch.tensor([5, 6], device=dev))
+        ops.check_message_ids()                                  # clean
 
 
 @pytest.mark.parametrize("training", [False, True])
