@@ -385,6 +385,7 @@ class LSTMFn(GradAwareFunction):
         dev, st = x.device, _stream()
         need_grad = wants_grad(ctx)
         h = torch.empty_like(x)
+        release_deferred_wgrads()                  # side stream: work queued for "beside the recurrence" starts now (eval_forward)
         if _LSTM_FUSED and T >= 8:                 # input projection inside the recurrence kernel (no xp tensor)
             gates = cst = None
             if need_grad:

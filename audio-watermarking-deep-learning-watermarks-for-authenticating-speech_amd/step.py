@@ -52,10 +52,26 @@ def train_step(generator, detector, optimizer, s, message, grad_sync=None):
 
 @torch.no_grad()
 def eval_forward(generator, detector, s, message):
-    """evaluate_model's per-batch quantities (:383-403)."""
+    """evaluate_model's per-batch quantities (:383-403).  In eval mode BatchNorm uses running statistics, so the Detector's
+    rows are independent: the clean half D(s) does not wait for the Generator -- it is queued for the side stream and released
+    when the Generator reaches its latency-bound LSTM (B clips keep only B of the 256 CUs busy there), and the two halves are
+    concatenated afterwards (bit-identical to the single 2B-row call)."""
+    from . import ops
     B = s.shape[0]
+    overlap = (not generator.training) and (not detector.training) and s.is_cuda
+    box = {}
+    if overlap:
+        def clean_half():
+            box["lg"] = detector(s)
+        ops._on_side((s,), clean_half)                # queued: released on the side stream when the LSTM launch is reached
     delta = L.postprocess(generator(s, message))
-    logits = detector(torch.cat([s + delta, s], dim=0))
+    if overlap:
+        lg_wm = detector(s + delta)
+        ops.join_side_stream()                        # (also releases the queue if the Generator had no LSTM call)
+        box["lg"].record_stream(torch.cuda.current_stream())
+        logits = torch.cat([lg_wm, box["lg"]], dim=0)
+    else:
+        logits = detector(torch.cat([s + delta, s], dim=0))
     probs = torch.sigmoid(logits[:, :, 0]).mean(dim=1)
     decoded = (torch.sigmoid(logits[:B, :, 1:]) > 0.5).float().mean(dim=1) > 0.5
     bits = ((message.unsqueeze(1) & (1 << torch.arange(logits.shape[-1] - 1, device=s.device))) > 0)
