@@ -661,23 +661,33 @@ __global__ __launch_bounds__(256, 3) void gwgrad2_kernel(GWArgs g) {
     }
 }
 
-// out[perm(i)] (+)= sum_z slab[z][i]: 8 z-lanes per output, each a fixed-order chain, combined in fixed order (fp64).
+// out[perm(i)] (+)= sum_z slab[z][i]: 8 z-lanes per output, each a fixed-order chain, combined in fixed order (fp64).  Outputs
+// i >= n are the bias gradient: bout[i - n] (+)= sum_z bslab[z][i - n] (nb of them; bslab / bout may be null with nb = 0).
 //   remap 0: identity | 1: column j' = k*r1 + b -> b*r2 + k (tap planes -> dW[a][b][k]; r1 = Cb, r2 = K)
 //        | 2: column j' = (co*r1 + ph)*2 + q -> co*2*r1 + q*r1 + ph (stride phases -> ConvTranspose taps; r1 = stride)
 __global__ __launch_bounds__(256) void gwgrad2_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out, size_t n, int nz,
-                                                             int NJ, int accumulate, int remap, int r1, int r2) {
+                                                             int NJ, int accumulate, int remap, int r1, int r2,
+                                                             const float* __restrict__ bslab, float* __restrict__ bout, int nb) {
     __shared__ double part[8][32];
     const int o = threadIdx.x & 31, zl = threadIdx.x >> 5;
     const size_t i = (size_t)blockIdx.x * 32 + o;
+    const bool is_w = i < n, is_b = !is_w && i < n + (size_t)nb;
     double s = 0.0;
-    if (i < n)
+    if (is_w)
         for (int z = zl; z < nz; z += 8) s += (double)slab[(size_t)z * n + i];
+    else if (is_b)
+        for (int z = zl; z < nz; z += 8) s += (double)bslab[(size_t)z * nb + (i - n)];
     part[zl][o] = s;
     __syncthreads();
-    if (zl == 0 && i < n) {
+    if (zl == 0 && (is_w || is_b)) {
         double t = 0.0;
 #pragma unroll
         for (int q = 0; q < 8; ++q) t += part[q][o];
+        if (is_b) {
+            float* d = bout + (i - n);
+            *d = (float)((accumulate ? (double)*d : 0.0) + t);
+            return;
+        }
         size_t d = i;
         if (remap) {
             const size_t a = i / (size_t)NJ;
@@ -741,20 +751,24 @@ GWPlan gw_plan(int NB, int Ca, int Cb, int La, int K) {
     const int TA = 32 * p.WA, R = 4 / p.WA, NJ = Cb * K;
     p.nta = (Ca + TA - 1) / TA;
     const int nsub_total = (NJ + 31) / 32;
-    p.WJW = 1;
-    while (p.WJW < R && nsub_total > 4 * p.WJW) p.WJW *= 2;
-    p.WT = R / p.WJW;
-    // 32-column blocks per wave (<= 4): the count that wastes the fewest matrix-core columns over all column tiles, the
-    // larger on ties; K = 1: every column is its own channel -- at most 128 staged rows
-    int best = 1, best_waste = 1 << 30;
-    for (int ns = 4; ns >= 1; --ns) {
-        const int tjb = p.WJW * ns;                                  // blocks per column tile
-        const int rows = (tjb * 32 - 1) / K + 2;                     // Bx rows such a tile touches
-        if (ns > 1 && (rows < Cb ? rows : Cb) > 4 * GW_RB) continue;  // more rows than the staging registers hold
-        const int waste = ((nsub_total + tjb - 1) / tjb) * tjb - nsub_total;
-        if (waste < best_waste) { best_waste = waste; best = ns; }
+    // wave split of the columns (WJW of the R waves that do not split rows) x 32-column blocks per wave (ns <= 4): the tile must
+    // not touch more Bx rows than the staging registers hold (K = 1: every column is its own row); among those, waste the fewest
+    // matrix-core columns over all column tiles, then take the widest tile (fewest re-reads of A), then the most column waves
+    int bw = 1, bn = 1, best_waste = 1 << 30, best_tj = 0;
+    for (int wjw = R; wjw >= 1; wjw >>= 1) {
+        for (int ns = 4; ns >= 1; --ns) {
+            const int tjb = wjw * ns;                                    // blocks per column tile
+            if (tjb > nsub_total && !(wjw == 1 && ns == 1) && (tjb - nsub_total) >= ns) continue;   // a whole wave would idle
+            int rows = (tjb * 32 - 1) / K + 2;
+            if (rows > Cb) rows = Cb;
+            if (rows > 4 * GW_RB && !(wjw == 1 && ns == 1)) continue;
+            const int waste = ((nsub_total + tjb - 1) / tjb) * tjb - nsub_total;
+            if (waste < best_waste || (waste == best_waste && tjb > best_tj)) { best_waste = waste; best_tj = tjb; bw = wjw; bn = ns; }
+        }
     }
-    p.nsub = best;
+    p.WJW = bw;
+    p.nsub = bn;
+    p.WT = R / p.WJW;
     {
         const int TJ0 = p.WJW * 32 * p.nsub;
         p.NBCH = (TJ0 - 1) / K + 2;
@@ -1064,14 +1078,10 @@ int wm_gwgrad(const float* A, const float* Bx, float* G, float* dbias, float* sl
 #undef WM_GW
     if (rc) return rc;
     const size_t n = (size_t)Ca * NJ;
-    hipLaunchKernelGGL(gwgrad2_reduce_kernel, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, stream, slab, G, n, p.gz, NJ, accumulate,
-                       remap, r1, r2);
+    const int nbias = dbias ? Ca : 0;
+    hipLaunchKernelGGL(gwgrad2_reduce_kernel, dim3((unsigned)((n + nbias + 31) / 32)), dim3(256), 0, stream, slab, G, n, p.gz, NJ, accumulate,
+                       remap, r1, r2, slabb, dbias, nbias);
     WM_CHECK_LAUNCH();
-    if (dbias) {
-        hipLaunchKernelGGL(gwgrad2_reduce_kernel, dim3((unsigned)((Ca + 31) / 32)), dim3(256), 0, stream, slabb, dbias, (size_t)Ca,
-                           p.gz, Ca, accumulate, 0, 0, 0);
-        WM_CHECK_LAUNCH();
-    }
     return 0;
 }
 
