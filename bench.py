@@ -86,9 +86,9 @@ def pmc_traffic(fname, prefixes):
         return None
 
 
-def cpu_baseline_main16(sample_batch=4, steps=1):
+def cpu_baseline_main16(sample_batch=2, steps=1):
     """The oracle (CPU restatement, kind "port") timed on this box's host cores on a bounded sample of the same workload:
-    B=4 train steps (fwd + bwd + Adam), 1 warm-up + `steps` timed (about 20-30 s of CPU work in all)."""
+    B=2 train steps (fwd + bwd + Adam), 1 warm-up + `steps` timed (about 15-20 s of CPU work in all)."""
     from oracle import recipes as R
     from oracle import wm_oracle as O
     nthreads = torch.get_num_threads()
@@ -118,7 +118,7 @@ def cpu_baseline_main16(sample_batch=4, steps=1):
                       f"{dt:.2f} s/step, torch CPU fp32 with {nthreads} threads"}
 
 
-def cpu_baseline_main14b2(G, D, sample_batch=4, steps=1):
+def cpu_baseline_main14b2(G, D, sample_batch=2, steps=1):
     """same for configs[4]: oracle/wm_oracle_14b2.py step (hidden 256) on the host cores, weights = the modules' own"""
     from oracle import wm_oracle as O
     from oracle import wm_oracle_14b2 as O2
