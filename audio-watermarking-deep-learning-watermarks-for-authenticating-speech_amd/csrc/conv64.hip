@@ -26,7 +26,9 @@ __device__ unsigned long long* g_wm_stamp = nullptr;
 namespace {
 
 enum { PRO_NONE = 0, PRO_BNRELU = 1, PRO_ADDVEC = 2, PRO_BNBWD = 3 };
-enum { EPI_BIAS = 0, EPI_RELUMASK = 1, EPI_ADD = 2, EPI_NONE = 3, EPI_BNADDRELU = 4 };   // 4: relu(e1 + (acc + bias) * ea + eb), conv64bf3 only
+enum { EPI_BIAS = 0, EPI_RELUMASK = 1, EPI_ADD = 2, EPI_NONE = 3, EPI_BNADDRELU = 4,    // 4: relu(e1 + (acc + bias) * ea + eb), conv64bf3 only
+       EPI_BIASELU = 5, EPI_BIASADDELU = 6, EPI_MULDELU = 7 };   // main14b_2's 64-channel blocks (conv64bf_kernel only): elu(acc + bias),
+                                                                 // elu(acc + bias + e1), acc * ELU'(e1) with e1 = the ELU output y
 
 struct Conv64Args {
     const float* x;     // [B,64,T] primary input
@@ -586,7 +588,8 @@ __global__ __launch_bounds__(256) void conv64bf_kernel(Conv64Args a) {
     constexpr int KW = 3, PAD = 1, NT = 128, ROWS = NT + 2, PITCH = 72, NP = 3;
     constexpr int NC = 4;                         // (channel pair, time quad) combos per thread
     constexpr bool TWO = (PRO == PRO_BNBWD);
-    constexpr bool E1 = (EPI == EPI_RELUMASK || EPI == EPI_ADD);
+    constexpr bool E1 = (EPI == EPI_RELUMASK || EPI == EPI_ADD || EPI == EPI_BIASADDELU || EPI == EPI_MULDELU);
+    constexpr bool HASBIAS = (EPI == EPI_BIAS || EPI == EPI_BIASELU || EPI == EPI_BIASADDELU);
     extern __shared__ __align__(16) unsigned char smem_raw[];
     unsigned short* Wb = reinterpret_cast<unsigned short*>(smem_raw);              // [NP][KW][64 out][PITCH]
     unsigned short* Xb = Wb + NP * KW * 64 * PITCH;                                // [NP][ROWS][PITCH]
@@ -674,7 +677,7 @@ __global__ __launch_bounds__(256) void conv64bf_kernel(Conv64Args a) {
         Cs[tid] = (PRO == PRO_BNRELU || PRO == PRO_BNBWD) ? a.pa[tid] : 0.f;
         Cs[64 + tid] = (PRO == PRO_BNRELU || PRO == PRO_BNBWD) ? a.pb[tid] : 0.f;
         Cs[128 + tid] = (PRO == PRO_BNBWD) ? a.pc[tid] : 0.f;
-        Cs[192 + tid] = (PRO == PRO_BNBWD) ? a.pb[64 + tid] : ((EPI == EPI_BIAS && a.bias) ? a.bias[tid] : 0.f);
+        Cs[192 + tid] = (PRO == PRO_BNBWD) ? a.pb[64 + tid] : ((HASBIAS && a.bias) ? a.bias[tid] : 0.f);
         Cs[256 + tid] = (EPI == EPI_RELUMASK) ? a.ea[tid] : 0.f;
         Cs[320 + tid] = (EPI == EPI_RELUMASK) ? a.eb[tid] : 0.f;
     }
@@ -752,9 +755,11 @@ __global__ __launch_bounds__(256) void conv64bf_kernel(Conv64Args a) {
                 const int co = mt * 32 + mfma_row(r, half);
                 float v = acc[mt][r];
                 float q = 0.f;
-                if (EPI == EPI_BIAS) v += Cs[192 + co];
+                if (HASBIAS) v += Cs[192 + co];
                 if (EPI == EPI_RELUMASK) { q = e1r[mt * 16 + r]; v = (fmaf(q, Cs[256 + co], Cs[320 + co]) > 0.f) ? v : 0.f; }
-                if (EPI == EPI_ADD) v += e1r[mt * 16 + r];
+                if (EPI == EPI_ADD || EPI == EPI_BIASADDELU) v += e1r[mt * 16 + r];
+                if (EPI == EPI_BIASELU || EPI == EPI_BIASADDELU) v = elu1(v);
+                if (EPI == EPI_MULDELU) { const float yy = e1r[mt * 16 + r]; v *= (yy > 0.f ? 1.f : yy + 1.f); }
                 if (ok) {
                     yb[(size_t)co * T] = v;
                     if (STATS) { s1[mt * 16 + r] += v; s2[mt * 16 + r] += (EPI == EPI_RELUMASK) ? v * q : v * v; }
@@ -2190,6 +2195,13 @@ int wm_conv64_bf(const float* x, const float* x2, const void* wpb, const float* 
     if (B <= 0 || T <= 0 || (T & 3)) return (int)hipErrorInvalidValue;
     Conv64Args a{x, x2, reinterpret_cast<const float*>(wpb), pa, pb, pc, bias, e1, ea, eb, y, stats, B, T};
     const bool st = stats != nullptr;
+    if (pro == PRO_NONE && !st) {        // main14b_2's 64-channel blocks (no BatchNorm): the phase-serial kernel, any T % 4 == 0
+        if (epi == EPI_BIASELU) return launch_conv64bf<PRO_NONE, EPI_BIASELU, false>(a, stream);
+        if (epi == EPI_BIASADDELU) return launch_conv64bf<PRO_NONE, EPI_BIASADDELU, false>(a, stream);
+        if (epi == EPI_MULDELU) return launch_conv64bf<PRO_NONE, EPI_MULDELU, false>(a, stream);
+        if (epi == EPI_ADD) return launch_conv64bf<PRO_NONE, EPI_ADD, false>(a, stream);
+        if (epi == EPI_NONE) return launch_conv64bf<PRO_NONE, EPI_NONE, false>(a, stream);
+    }
     if (g_bf_schedule == 2 && (T & 127) == 0) {
         if (pro == PRO_BNRELU && epi == EPI_BNADDRELU && !st) return launch_conv64bf3<PRO_BNRELU, EPI_BNADDRELU, false>(a, stream);
         if (pro == PRO_NONE && epi == EPI_BIAS) return st ? launch_conv64bf3<PRO_NONE, EPI_BIAS, true>(a, stream) : launch_conv64bf3<PRO_NONE, EPI_BIAS, false>(a, stream);
@@ -2260,6 +2272,8 @@ int wm_wgrad64_bf(const float* g, const float* g2, const float* ga, const float*
         rc = small ? launch_wgrad64bf_small<PRO_BNBWD, PRO_BNRELU>(a, &grid, stream) : launch_wgrad64bf<PRO_BNBWD, PRO_BNRELU>(a, &grid, stream);
     else if (gpro == PRO_BNBWD && xpro == PRO_NONE)
         rc = small ? launch_wgrad64bf_small<PRO_BNBWD, PRO_NONE>(a, &grid, stream) : launch_wgrad64bf<PRO_BNBWD, PRO_NONE>(a, &grid, stream);
+    else if (gpro == PRO_NONE && xpro == PRO_NONE)            // main14b_2's 64-channel blocks: both operands as they are
+        rc = launch_wgrad64bf<PRO_NONE, PRO_NONE>(a, &grid, stream);
     if (rc) return rc;
     const int n = 3 * 4096 + 64;
     hipLaunchKernelGGL(wgrad64_reduce_kernel, dim3((n + 63) / 64), dim3(256), 0, stream, (const float*)partial, grid, 3, 0, dw,

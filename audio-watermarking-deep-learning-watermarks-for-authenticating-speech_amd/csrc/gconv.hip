@@ -38,14 +38,6 @@ struct GConvArgs {
 constexpr int kr_max_of(int bm) { return bm >= 128 ? 36 : 48; }
 constexpr int xr_of(int bn) { return bn >= 256 ? 16 : 10; }   // input-tile elements a thread stages per chunk, by tile width
 
-// ELU (alpha = 1) with a cheap expm1: Taylor to the 6th order on (-0.35, 0] (error < 4e-7 of the value), exp(v) - 1 below
-__device__ __forceinline__ float elu1(float v) {
-    const float p = v * (1.f + v * (0.5f + v * (0.16666667f + v * (0.041666668f + v * (0.0083333338f + v * 0.0013888889f)))));
-    const float e = __expf(v) - 1.f;
-    const float n = v > -0.35f ? p : e;
-    return v > 0.f ? v : n;
-}
-
 typedef __amdgpu_buffer_rsrc_t wm_srd_t;   // 128-bit buffer resource descriptor (kept in scalar registers)
 
 // buffer descriptor over [p, p + bytes): 32-bit per-lane byte offsets + a scalar offset, reads past the end return 0

@@ -118,6 +118,16 @@ __device__ __forceinline__ double block_sum_d(double v, double* scratch) {
 
 __device__ __forceinline__ float sigmoidf_acc(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+// ELU (alpha = 1) with a cheap expm1: Taylor to the 6th order on (-0.35, 0] (error < 4e-7 of the value), exp(v) - 1 below
+__device__ __forceinline__ float elu1(float v) {
+    const float p = v * (1.f + v * (0.5f + v * (0.16666667f + v * (0.041666668f + v * (0.0083333338f + v * 0.0013888889f)))));
+    const float e = __expf(v) - 1.f;
+    const float n = v > -0.35f ? p : e;
+    return v > 0.f ? v : n;
+}
+
+
+
 // ---- bf16x6 split arithmetic (see conv64.hip): x = hi + mid + lo as three bf16 pieces, exact to 24 bits
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));

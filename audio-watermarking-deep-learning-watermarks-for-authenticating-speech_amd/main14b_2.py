@@ -34,8 +34,28 @@ def _gconv_raw(x, wp, bias, K, S, P, Mtot, Nout, st, shp, Cout, Lout, act=0, res
     return y
 
 
+# ---- the 64 -> 64, k3, stride-1 convolutions of this variant (conv2 of the first encoder block, the 64-channel decoder blocks) are
+# the SAME shape as main16's ResBlock convolution: they run on its bf16x6 kernels (csrc/conv64.hip, fp32-grade arithmetic on the
+# bf16 matrix cores, ~1.7x the rate of the generic fp32-MFMA kernel), with ELU-family epilogues instead of BatchNorm ones.
+def _c64_ok(w, stride, padding, L):
+    return (tuple(w.shape) == (64, 64, 3) and stride == 1 and padding == 1 and L % 4 == 0 and L >= 4 and ops.conv_bf16x6())
+
+
+def _c64_conv(x, w, mode, bias, e1, epi):
+    """mode 0 forward | 1 data gradient (wm_pack_w64_bf); epi 5 elu(.+bias) | 6 elu(.+bias+e1) | 7 .*ELU'(e1) | 2 .+e1 | 3 | 0 .+bias"""
+    B, _, L = x.shape
+    y = torch.empty_like(x)
+    lib.wm_conv64_bf(_p(x), None, _p(ops.pack_w64_bf(w, mode)), None, None, None, _p(bias), _p(e1), None, None, _p(y), None, B, L, 0, epi,
+                     _stream())
+    return y
+
+
 def _conv_fwd(x, w, bias, stride, padding, act=0, res=None, vec=None):
     Cout, Cin, K = w.shape
+    if vec is None and bias is not None and _c64_ok(w, stride, padding, x.shape[2]) and (act == 1 or res is None):
+        if act == 1:
+            return _c64_conv(x, w, 0, bias, res, 6 if res is not None else 5)
+        return _c64_conv(x, w, 0, bias, None, 0)
     Lout = (x.shape[2] + 2 * padding - K) // stride + 1
     wp = w.permute(1, 2, 0).reshape(Cin * K, Cout).contiguous()
     return _gconv_raw(x, wp, bias, K, stride, padding, Cout, Lout, 1, 0, Cout, Lout, act, res, vec)
@@ -45,6 +65,8 @@ def _conv_dgrad(g, w, stride, padding, Lin, res=None, act=0, out=None):
     """dL/dx of Conv1d(w [Cout,Cin,K], stride, padding) for dL/dy = g [NB,Cout,Lout]; epilogue: + res (act 0) or, act 2,
     multiplied by ELU'(res) (res = the ELU output the gradient flows into: the result is dL/dz)"""
     Cout, Cin, K = w.shape
+    if out is None and _c64_ok(w, stride, padding, Lin) and g.shape[2] == Lin:
+        return _c64_conv(g, w, 1, None, res, 7 if act == 2 else (2 if res is not None else 3))
     if stride == 1:
         wp = w.flip(2).permute(0, 2, 1).reshape(Cout * K, Cin).contiguous()             # rows (co, kk): W[co][ci][K-1-kk]
         return _gconv_raw(g, wp, None, K, 1, K - 1 - padding, Cin, Lin, 1, 0, Cin, Lin, act, res, None, None, 0, out)
@@ -112,6 +134,12 @@ def _conv_wgrad(gz, x, w_shape, stride, padding, want_bias, planes=None):
     the K tap planes of x out as channels (x'[k*Cin + ci][t] = x[ci][t*stride + k - padding]): its weight gradient is then a
     K = 1 stride-1 GEMM over K*Cin channels (`planes` = an already gathered x', shared with the block's 1x1 skip conv)."""
     Cout, Cin, K = w_shape
+    if tuple(w_shape) == (64, 64, 3) and stride == 1 and padding == 1 and x.shape[2] % 4 == 0 and ops.conv_bf16x6():
+        B, _, L = x.shape
+        dw, db = torch.empty(w_shape, dtype=torch.float32, device=x.device), _f32(64, device=x.device)
+        part = _f32(2 * ops.NCU * (3 * 4096 + 64), device=x.device)
+        lib.wm_wgrad64_bf(_p(gz), None, None, None, None, _p(x), None, None, _p(part), _p(dw), _p(db), B, L, 0, 0, 0, _stream())
+        return dw, (db if want_bias else None)
     if stride == 1:
         return _gwgrad_raw(gz, x, Cin, x.shape[2], 0, w_shape, K, padding, want_bias)
     Lout = gz.shape[2]

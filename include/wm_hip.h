@@ -53,7 +53,10 @@ int wm_conv64(const float* x, const float* x2, const float* wp, const float* pa,
  * (mode 0 Conv1d fwd | 1 Conv1d dgrad).  One more epilogue exists here only, for inference (py/main16.py:124-125 in
  * eval mode as two launches): (pro 1, epi 4, stats NULL) y = relu(e1 + (conv + bias[c]) * ea[c] + eb[c]), i.e. the
  * second conv of a ResBlock with BatchNorm2 (folded running statistics), the residual add and the ReLU in its epilogue;
- * needs schedule 2 and T % 128 == 0 (hipErrorInvalidValue otherwise). */
+ * needs schedule 2 and T % 128 == 0 (hipErrorInvalidValue otherwise).
+ * For the 64-channel stride-1 blocks of the main14b_2 variant (py/main14b_2.py:95-102, no BatchNorm; pro 0, stats NULL, any
+ * T % 4 == 0, phase-serial kernel): epi 5 y = elu(conv + bias) | 6 y = elu(conv + bias + e1) | 7 y = conv * ELU'(e1), e1 = the ELU
+ * output the gradient flows into | 2 y = conv + e1 | 3 y = conv. */
 int wm_pack_w64_bf(const float* w, void* wpb, int mode, wm_stream_t stream);
 /* schedule of wm_conv64_bf (process-wide knob; default 2): 0 phase-serial, one wave per SIMD, 128-column tiles |
  * 1 two groups of four waves half a period apart, 64-column tiles | 2 weight fragments resident in registers, input
@@ -74,7 +77,7 @@ int wm_conv64_bf7(const float* x, const void* wpb, const float* vec, const float
 int wm_wgrad64_bf7(const float* g, const float* x, const float* vec, float* partial, float* dw, float* dbias, int B, int T,
                    int xpro, int accumulate, wm_stream_t stream);
 
-/* bf16x6 build of the k3 Conv1d weight gradient (contract of wm_wgrad64 with KW = 3, layout 0).  accumulate: bit 0 = add to
+/* bf16x6 build of the k3 Conv1d weight gradient (contract of wm_wgrad64 with KW = 3, layout 0; gpro / xpro (3,1), (3,0), (0,0)).  accumulate: bit 0 = add to
  * dw / dbias, bit 1 = the output-split build (a wave keeps one 32x32 block per tap: ~200 registers per lane, so the workgroup
  * can share a CU with the LSTM recurrence kernels when it is launched on a side stream; same results)                     */
 int wm_wgrad64_bf(const float* g, const float* g2, const float* ga, const float* gb, const float* gc,
