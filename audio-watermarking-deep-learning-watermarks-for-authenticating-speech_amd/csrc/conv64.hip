@@ -1147,6 +1147,276 @@ int launch_conv64bf3(const Conv64Args& a, hipStream_t stream) {
 
 
 // ---------------------------------------------------------------------------------------------
+// Inference ResBlock in ONE launch:  out = relu(x + BN2(conv2(relu(BN1(conv1(x))))))  with both BatchNorms in eval
+// mode (running statistics folded into per-channel scale / shift), py/main16.py:112-125.  Frame passes over HBM: x in,
+// out out -- the intermediate never leaves the CU.
+// A workgroup walks 124-column output tiles.  Its x window is the 128 columns [w0, w0+128), w0 = 124 k - 4: exactly 32
+// aligned float4 per channel, no halo loads.  conv1 runs over MFMA columns j = 0..127 (a1 at time w0 + 1 + j, valid for
+// j < 126), its epilogue applies BN1 + ReLU (and the zero padding of conv2: a1 = 0 outside the clip), splits the result
+// into its three bf16 pieces and writes them to a second LDS image; conv2 reads that image (output column i = time
+// w0 + 2 + i, valid for i < 124) and its epilogue adds BN2 and the residual x (re-read from L2 in accumulator layout) and
+// stores.  Both convolutions keep the weight fragments of the wave's 32 output rows in registers (2 x 144 VGPRs of the
+// 512 a lone wave may use), so LDS holds only the two activation images (2 x 55 KB).  While conv2 runs, the same
+// instruction stream splits the NEXT tile's x window into the (by then free) x image; while conv1 runs, it fetches the
+// residual operand.
+// ---------------------------------------------------------------------------------------------
+struct RbeArgs {
+    const float* x;       // [B,64,T]
+    const void* w1;       // packed bf16 image [3 pieces][3 taps][64 out][64 in] (wm_pack_w64_bf, mode 0)
+    const void* w2;
+    const float* b1; const float* sc1; const float* sh1;     // conv bias, folded BN scale / shift
+    const float* b2; const float* sc2; const float* sh2;
+    float* y;             // [B,64,T]
+    int B, T;
+};
+
+__global__ __launch_bounds__(256) void resblock_eval_kernel(RbeArgs a) {
+    constexpr int KW = 3, NTO = 124, ROWS = 130, PITCH = 72, NP = 3, NC = 4;
+    constexpr int XBUF = NP * ROWS * PITCH;               // bf16 elements per image
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    unsigned short* Xb = reinterpret_cast<unsigned short*>(smem_raw);              // x window: row r = time w0 + r
+    unsigned short* Ab = Xb + XBUF;                                                // a1: row j = time w0 + 1 + j
+    float* Cs = reinterpret_cast<float*>(Ab + XBUF);                               // [4][64]: k1a k1b k2a k2b
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int mt = wave & 1, nh = wave >> 1;
+    const int T = a.T;
+    const int tilesPerClip = (T + 2 + NTO - 1) / NTO, ntiles = a.B * tilesPerClip;
+
+    bf16x8 W1[12][NP], W2[12][NP];
+    {
+        const uint4* wg1 = reinterpret_cast<const uint4*>(a.w1);
+        const uint4* wg2 = reinterpret_cast<const uint4*>(a.w2);
+#pragma unroll
+        for (int s = 0; s < 12; ++s)
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                const int e = ((p * KW + (s >> 2)) * 64 + 32 * mt + l31) * 64 + 16 * (s & 3) + 8 * half;
+                W1[s][p] = __builtin_bit_cast(bf16x8, wg1[e >> 3]);
+                W2[s][p] = __builtin_bit_cast(bf16x8, wg2[e >> 3]);
+            }
+    }
+    // staging map (fixed per thread): channel pair cp, time quads q0 + 8 i
+    const int cp = wave * 8 + (lane & 7), c0 = 2 * cp, q0 = lane >> 3;
+    float4 sa[NC], sb[NC];
+    auto load_combo = [&](int tile, int i) {      // branch-free: clamped address, masked when written to LDS
+        const int b = tile / tilesPerClip, w0 = (tile - b * tilesPerClip) * NTO - 4;
+        const int t = min(max(w0 + 4 * (q0 + 8 * i), 0), T - 4);
+        const size_t o = ((size_t)b * 64 + c0) * T + t;
+        sa[i] = *reinterpret_cast<const float4*>(a.x + o);
+        sb[i] = *reinterpret_cast<const float4*>(a.x + o + T);
+    };
+    auto split_unit = [&](int w0, int i, int e) {  // two channels x one time step of the window starting at w0 -> 3 dwords
+        const int t = w0 + 4 * (q0 + 8 * i);
+        const bool ok = (t >= 0) && (t < T);        // T % 4 == 0 and w0 % 4 == 0: a quad is inside or outside as a whole
+        const float4 fa = sa[i], fb = sb[i];
+        float va = (e == 0) ? fa.x : (e == 1) ? fa.y : (e == 2) ? fa.z : fa.w;
+        float vb = (e == 0) ? fb.x : (e == 1) ? fb.y : (e == 2) ? fb.z : fb.w;
+        va = ok ? va : 0.f; vb = ok ? vb : 0.f;
+        unsigned p0, p1, p2;
+        split3_pair(va, vb, p0, p1, p2);
+        unsigned* X32 = reinterpret_cast<unsigned*>(Xb);
+        const int o = (4 * (q0 + 8 * i) + e) * (PITCH / 2) + cp;
+        X32[o] = p0; X32[(ROWS * PITCH >> 1) + o] = p1; X32[2 * (ROWS * PITCH >> 1) + o] = p2;
+    };
+
+    const int tstep = gridDim.x;
+    int tile = xcd_slot();                                         // grid <= ntiles
+#pragma unroll
+    for (int i = 0; i < NC; ++i) load_combo(tile, i);
+    if (tid < 64) {
+        const float s1 = a.sc1[tid], s2 = a.sc2[tid];
+        Cs[tid] = s1;
+        Cs[64 + tid] = fmaf(a.b1 ? a.b1[tid] : 0.f, s1, a.sh1[tid]);
+        Cs[128 + tid] = s2;
+        Cs[192 + tid] = fmaf(a.b2 ? a.b2[tid] : 0.f, s2, a.sh2[tid]);
+    }
+    // rows 128, 129 of both images are read by the discarded MFMA columns only: keep them finite (zero)
+    for (int i = tid; i < NP * 2 * (PITCH / 2); i += 256) {
+        const int p = i / (2 * (PITCH / 2)), rem = i - p * (2 * (PITCH / 2));
+        const int o = (p * ROWS + 128) * (PITCH / 2) + rem;
+        reinterpret_cast<unsigned*>(Xb)[o] = 0u;
+        reinterpret_cast<unsigned*>(Ab)[o] = 0u;
+    }
+    {
+        const int w0 = (tile % tilesPerClip) * NTO - 4;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) split_unit(w0, u >> 2, u & 3);
+    }
+    {
+        const int nx = min(tile + tstep, ntiles - 1);
+#pragma unroll
+        for (int i = 0; i < NC; ++i) load_combo(nx, i);
+    }
+    __syncthreads();
+
+    float e1r[32];
+
+    while (tile < ntiles) {
+        const int next = min(tile + tstep, ntiles - 1), next2 = min(tile + 2 * tstep, ntiles - 1);
+        const int b = tile / tilesPerClip, w0 = (tile - b * tilesPerClip) * NTO - 4, o0 = w0 + 2;
+        const int nw0 = (next % tilesPerClip) * NTO - 4;
+        // output column of accumulator block nt of this lane, and its clamped time (residual loads)
+        int tcl[2];
+        bool okv[2];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int i = 64 * nh + 32 * nt + l31, t = o0 + i;
+            okv[nt] = (i < NTO) && (t >= 0) && (t < T);
+            tcl[nt] = min(max(t, 0), T - 1) + 4 * half * T;
+        }
+        auto rowbase = [&](int r) { return ((size_t)b * 64 + 32 * mt + (r & 3) + 8 * (r >> 2)) * T; };   // wave-uniform
+
+        // ---------------- conv1 from the x image (side work: residual operand loads)
+        f32x16 acc[2];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+        {
+            const unsigned short* xrow = Xb + (64 * nh + l31) * PITCH + 8 * half;
+            bf16x8 Bq[2][NP];
+#pragma unroll
+            for (int p = 0; p < NP; ++p) Bq[0][p] = *reinterpret_cast<const bf16x8*>(xrow + p * ROWS * PITCH);
+#pragma unroll
+            for (int h = 0; h < 24; ++h) {
+                const int s = h >> 1, nt = h & 1;
+                if (h + 1 < 24) {
+                    const int s1_ = (h + 1) >> 1, n1 = (h + 1) & 1;
+#pragma unroll
+                    for (int p = 0; p < NP; ++p)
+                        Bq[(h + 1) & 1][p] = *reinterpret_cast<const bf16x8*>(xrow + (p * ROWS + 32 * n1 + (s1_ >> 2)) * PITCH + 16 * (s1_ & 3));
+                }
+                const bf16x8* Bf = Bq[h & 1];
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W1[s][1], Bf[1], acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W1[s][0], Bf[2], acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W1[s][2], Bf[0], acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W1[s][0], Bf[1], acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W1[s][1], Bf[0], acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W1[s][0], Bf[0], acc[nt], 0, 0, 0);
+                if (h < 16) {
+                    e1r[2 * h] = (a.x + rowbase((2 * h) & 15))[tcl[(2 * h) >> 4]];
+                    e1r[2 * h + 1] = (a.x + rowbase((2 * h + 1) & 15))[tcl[(2 * h + 1) >> 4]];
+                }
+                __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+#pragma unroll
+                for (int kk = 0; kk < 6; ++kk) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // ---------------- epilogue 1: BN1 + ReLU, zero outside the clip, split, a1 image
+        {
+            unsigned* A32 = reinterpret_cast<unsigned*>(Ab);
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const int j = 64 * nh + 32 * nt + l31, u = w0 + 1 + j;
+                const bool in = (u >= 0) && (u < T);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int c4 = 32 * mt + 8 * g + 4 * half;           // the lane's four consecutive channels of row group g
+                    const float4 ka = *reinterpret_cast<const float4*>(Cs + c4), kb = *reinterpret_cast<const float4*>(Cs + 64 + c4);
+                    const float kav[4] = {ka.x, ka.y, ka.z, ka.w}, kbv[4] = {kb.x, kb.y, kb.z, kb.w};
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float z = fmaxf(fmaf(acc[nt][4 * g + e], kav[e], kbv[e]), 0.f);
+                        v[e] = in ? z : 0.f;
+                    }
+                    unsigned pa0, pa1, pa2, pb0, pb1, pb2;
+                    split3_pair(v[0], v[1], pa0, pa1, pa2);
+                    split3_pair(v[2], v[3], pb0, pb1, pb2);
+                    const int o = (j * PITCH + 32 * mt + 8 * g + 4 * half) >> 1;
+                    *reinterpret_cast<uint2*>(A32 + o) = make_uint2(pa0, pb0);
+                    *reinterpret_cast<uint2*>(A32 + (ROWS * PITCH >> 1) + o) = make_uint2(pa1, pb1);
+                    *reinterpret_cast<uint2*>(A32 + 2 * (ROWS * PITCH >> 1) + o) = make_uint2(pa2, pb2);
+                }
+            }
+        }
+        lds_barrier();          // a1 image complete; every wave is done with the x image
+        // ---------------- conv2 from the a1 image (side work: split the next tile's x window, fetch the one after)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+        {
+            const unsigned short* xrow = Ab + (64 * nh + l31) * PITCH + 8 * half;
+            bf16x8 Bq[2][NP];
+#pragma unroll
+            for (int p = 0; p < NP; ++p) Bq[0][p] = *reinterpret_cast<const bf16x8*>(xrow + p * ROWS * PITCH);
+#pragma unroll
+            for (int h = 0; h < 24; ++h) {
+                const int s = h >> 1, nt = h & 1;
+                if (h + 1 < 24) {
+                    const int s1_ = (h + 1) >> 1, n1 = (h + 1) & 1;
+#pragma unroll
+                    for (int p = 0; p < NP; ++p)
+                        Bq[(h + 1) & 1][p] = *reinterpret_cast<const bf16x8*>(xrow + (p * ROWS + 32 * n1 + (s1_ >> 2)) * PITCH + 16 * (s1_ & 3));
+                }
+                const bf16x8* Bf = Bq[h & 1];
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W2[s][1], Bf[1], acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W2[s][0], Bf[2], acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W2[s][2], Bf[0], acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W2[s][0], Bf[1], acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W2[s][1], Bf[0], acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W2[s][0], Bf[0], acc[nt], 0, 0, 0);
+                if (h < 16) {
+                    split_unit(nw0, h >> 2, h & 3);
+                    if ((h & 3) == 3) load_combo(next2, h >> 2);       // this combo's registers are free again
+                }
+                __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+#pragma unroll
+                for (int kk = 0; kk < 6; ++kk) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // ---------------- epilogue 2: BN2 + residual + ReLU, store
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            if (okv[nt]) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int c4 = 32 * mt + 8 * g + 4 * half;
+                    const float4 ka = *reinterpret_cast<const float4*>(Cs + 128 + c4), kb = *reinterpret_cast<const float4*>(Cs + 192 + c4);
+                    const float kav[4] = {ka.x, ka.y, ka.z, ka.w}, kbv[4] = {kb.x, kb.y, kb.z, kb.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int r = 4 * g + e;
+                        const float v = fmaxf(e1r[nt * 16 + r] + fmaf(acc[nt][r], kav[e], kbv[e]), 0.f);
+                        (a.y + rowbase(r))[tcl[nt]] = v;
+                    }
+                }
+            }
+        }
+        lds_barrier();          // next x image complete; a1 image free
+        tile += tstep;
+    }
+}
+
+static int launch_resblock_eval(const RbeArgs& a, hipStream_t stream) {
+    constexpr size_t lds = (size_t)(2 * 3 * 130 * 72) * 2 + 4 * 64 * sizeof(float);
+    static wm::DevOnce attr_done;
+    if (!wm::dev_done(attr_done)) {
+        WM_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(resblock_eval_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        wm::dev_mark(attr_done);
+    }
+    const int ntiles = a.B * ((a.T + 2 + 123) / 124);
+    const int grid = ntiles < kNumCU ? ntiles : kNumCU;
+    hipLaunchKernelGGL(resblock_eval_kernel, dim3(grid), dim3(256), lds, stream, a);
+    WM_CHECK_LAUNCH();
+    return 0;
+}
+
+
+// ---------------------------------------------------------------------------------------------
 // bf16x6 convolution, two-group ("ping-pong") schedule.  The bf16 MFMA does not share the VALU pipe (the fp32 MFMA
 // does -- that is why this schedule lost with the native build), so with two waves per SIMD the split conversions,
 // LDS writes, global loads and the epilogue of one group run beside the matrix phase of the other.
@@ -2225,6 +2495,15 @@ int wm_conv64_bf(const float* x, const float* x2, const void* wpb, const float* 
     if (pro == PRO_BNBWD && epi == EPI_ADD && !st) return launch_conv64bf<PRO_BNBWD, EPI_ADD, false>(a, stream);
     if (pro == PRO_BNBWD && epi == EPI_NONE && !st) return launch_conv64bf<PRO_BNBWD, EPI_NONE, false>(a, stream);
     return (int)hipErrorInvalidValue;
+}
+
+// inference ResBlock in one launch (both BatchNorms folded): see resblock_eval_kernel
+int wm_resblock_eval_bf(const float* x, const void* w1pb, const void* w2pb, const float* b1, const float* sc1, const float* sh1,
+                        const float* b2, const float* sc2, const float* sh2, float* y, int B, int T, hipStream_t stream) {
+    if (B <= 0 || T <= 0 || (T & 3)) return (int)hipErrorInvalidValue;
+    if (!x || !w1pb || !w2pb || !sc1 || !sh1 || !sc2 || !sh2 || !y) return (int)hipErrorInvalidValue;
+    RbeArgs a{x, w1pb, w2pb, b1, sc1, sh1, b2, sc2, sh2, y, B, T};
+    return launch_resblock_eval(a, stream);
 }
 
 // bf16x6 build of the 7-tap ConvTranspose1d (forward: mode 2 image, pro 0|2, epi 0; data gradient: mode 3 image, pro 0, epi 3)

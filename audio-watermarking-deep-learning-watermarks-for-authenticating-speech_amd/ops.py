@@ -145,7 +145,8 @@ def _on_side(inputs, fn, defer=True):
 # k3 convolutions (forward + data gradient): native fp32 MFMA, or the bf16x6 split build (fp32-grade error on the
 # bf16 matrix cores, see csrc/conv64.hip).  WM_CONV_BF16X6=0/1 in the environment overrides the default.
 import os as _os
-_CONV = {"bf16x6": _os.environ.get("WM_CONV_BF16X6", "1") == "1", "schedule": 2}
+_CONV = {"bf16x6": _os.environ.get("WM_CONV_BF16X6", "1") == "1", "schedule": 2,
+         "one_launch_eval": _os.environ.get("WM_RESBLOCK_ONE_LAUNCH", "1") == "1"}
 
 
 def set_conv_bf_schedule(schedule: int):
@@ -160,6 +161,12 @@ if "WM_CONV_BF_SCHEDULE" in _os.environ:
 
 def set_conv_bf16x6(on: bool):
     _CONV["bf16x6"] = bool(on)
+
+
+def set_resblock_one_launch(on: bool):
+    """inference ResBlock: one launch (wm_resblock_eval_bf, default) or the two-launch form (conv1; conv2 with BN2 + add + ReLU
+    in its epilogue).  WM_RESBLOCK_ONE_LAUNCH=0/1 in the environment sets the default."""
+    _CONV["one_launch_eval"] = bool(on)
 
 
 def conv_bf16x6() -> bool:
@@ -203,10 +210,11 @@ class ResBlockFn(GradAwareFunction):
         x = _frames(x, "ResBlock input", 64)
         B, _, T = x.shape
         dev, st = x.device, _stream()
-        y1, y2, out = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+        out = torch.empty_like(x)
         cst = _f32(8, 64, device=dev)       # sc1 sh1 mean1 is1 sc2 sh2 mean2 is2
         sc1, sh1, mu1, is1, sc2, sh2, mu2, is2 = cst.unbind(0)
         if training:
+            y1, y2 = torch.empty_like(x), torch.empty_like(x)
             stats = _f32(NCU * 128, device=dev)
             _conv3(x, None, w1, 0, None, None, None, b1, None, None, None, y1, stats, B, T, 0, 0)
             lib.wm_bn_finalize(_p(stats), NCU, float(B * T), _p(g1), _p(be1), _p(rm1), _p(rv1), _p(nbt1), BN_MOMENTUM, BN_EPS,
@@ -217,11 +225,18 @@ class ResBlockFn(GradAwareFunction):
         else:
             lib.wm_bn_eval_scale_shift(_p(g1), _p(be1), _p(rm1), _p(rv1), BN_EPS, _p(sc1), _p(sh1), st)
             lib.wm_bn_eval_scale_shift(_p(g2), _p(be2), _p(rm2), _p(rv2), BN_EPS, _p(sc2), _p(sh2), st)
+            if not wants_grad(ctx) and _CONV["bf16x6"] and _CONV["one_launch_eval"]:
+                # inference: the whole block is ONE launch -- x in, out out, the intermediate activation stays in LDS
+                wp1, wp2 = pack_w64_bf(w1, 0), pack_w64_bf(w2, 0)       # both images must be alive at the launch
+                lib.wm_resblock_eval_bf(_p(x), _p(wp1), _p(wp2), _p(b1), _p(sc1), _p(sh1), _p(b2), _p(sc2), _p(sh2), _p(out), B, T, st)
+                return out
+            y1 = torch.empty_like(x)
             _conv3(x, None, w1, 0, None, None, None, b1, None, None, None, y1, None, B, T, 0, 0)
             if not wants_grad(ctx) and _CONV["bf16x6"] and _CONV["schedule"] == 2 and T % 128 == 0:
                 # inference: BN2 + residual add + ReLU ride in conv2's epilogue -- the block is two launches
                 _conv3(y1, None, w2, 0, sc1, sh1, None, b2, x, sc2, sh2, out, None, B, T, 1, 4)
                 return out
+            y2 = torch.empty_like(x)
             _conv3(y1, None, w2, 0, sc1, sh1, None, b2, None, None, None, y2, None, B, T, 1, 0)
             # saved (mean, invstd) for an eval-mode backward = running statistics
             mu1.copy_(rm1); is1.copy_(torch.rsqrt(rv1 + BN_EPS)); mu2.copy_(rm2); is2.copy_(torch.rsqrt(rv2 + BN_EPS))

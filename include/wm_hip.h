@@ -66,6 +66,13 @@ int wm_conv64_bf(const float* x, const float* x2, const void* wpb, const float* 
                  const float* bias, const float* e1, const float* ea, const float* eb, float* y, float* stats,
                  int B, int T, int pro, int epi, wm_stream_t stream);
 
+/* Inference ResBlock as ONE launch (py/main16.py:112-125 with both BatchNorm1d in eval mode):
+ *   y = relu(x + (conv2(relu((conv1(x) + b1) * sc1 + sh1)) + b2) * sc2 + sh2)
+ * sc / sh = the folded running statistics (wm_bn_eval_scale_shift), w1pb / w2pb = wm_pack_w64_bf mode-0 images, b1 / b2 may be
+ * NULL.  Two frame passes over HBM (x in, y out): the intermediate activation stays in LDS as bf16x3 pieces.  T % 4 == 0. */
+int wm_resblock_eval_bf(const float* x, const void* w1pb, const void* w2pb, const float* b1, const float* sc1, const float* sh1,
+                        const float* b2, const float* sc2, const float* sh2, float* y, int B, int T, wm_stream_t stream);
+
 /* bf16x6 build of the 7-tap ConvTranspose1d(64,64,7,padding=3) (py/main16.py:144): wpb [3][7][64][64] uint16 from
  * wm_pack_w64_bf7 (mode 2 forward | 3 data gradient).  pro 0 x | 2 x + vec[b*64+c]; epi 0 + bias[c] | 3 none. */
 int wm_pack_w64_bf7(const float* w, void* wpb, int mode, wm_stream_t stream);

@@ -142,39 +142,53 @@ def _resblock_state(seed):
     return sd
 
 
-@pytest.mark.parametrize("B,T", [(2, 1280), (1, 16000)])
-def test_resblock_inference_fused_epilogue(awm, dev, B, T):
-    """no-grad eval ResBlock = two launches (BN2 + residual + ReLU in conv2's epilogue, wm_conv64_bf epi 4): identical
-    to the three-launch path that autograd takes, and to the oracle (py/main16.py:124-125, eval mode)."""
+@pytest.mark.parametrize("B,T,one_launch", [(2, 1280, True), (1, 16000, True), (3, 1000, True), (2, 124, True), (1, 8, True),
+                                            (2, 1280, False), (1, 16000, False)])
+def test_resblock_inference_fused_epilogue(awm, dev, B, T, one_launch):
+    """no-grad eval ResBlock (py/main16.py:124-125, eval mode).  Default: ONE launch (wm_resblock_eval_bf: conv1 + BN1 + ReLU,
+    the intermediate kept in LDS, conv2 + BN2 + residual + ReLU), any T % 4 == 0 -- tile seams at multiples of 124, clip edges
+    and clips shorter than a tile are in the cases.  The two-launch form (BN2 + residual + ReLU in conv2's epilogue,
+    wm_conv64_bf epi 4) stays selectable.  Both against the three-launch path autograd takes and against the oracle."""
     sd = _resblock_state(21 + B)
     x = rnd(B, 64, T, seed=13).abs() * 0.7
     m = awm.ResBlock(64)
     m.load_state_dict(sd)
     m.to(dev).eval()
     assert all(p.requires_grad for p in m.parameters())      # default-constructed module: the parameters are trainable
-    calls = []
-    orig = awm.lib.wm_conv64_bf
+    calls, whole = [], []
+    orig, orig_rb = awm.lib.wm_conv64_bf, awm.lib.wm_resblock_eval_bf
 
     def spy(*a):
         calls.append(a[15])                                   # epi argument
         return orig(*a)
-    awm.lib.wm_conv64_bf = spy
+
+    def spy_rb(*a):
+        whole.append((a[10], a[11]))                          # B, T
+        return orig_rb(*a)
+    awm.lib.wm_conv64_bf, awm.lib.wm_resblock_eval_bf = spy, spy_rb
+    awm.ops.set_resblock_one_launch(one_launch)
     try:
         with torch.no_grad():
             y_fused = m(x.to(dev))
-        fused_calls = list(calls)
-        del calls[:]
+        fused_calls, fused_whole = list(calls), list(whole)
+        del calls[:], whole[:]
         y_unfused = m(x.to(dev).requires_grad_())          # grad mode on + an input gradient wanted -> the unfused path
-        unfused_calls = list(calls)
+        unfused_calls, unfused_whole = list(calls), list(whole)
     finally:
-        awm.lib.wm_conv64_bf = orig
+        awm.lib.wm_conv64_bf, awm.lib.wm_resblock_eval_bf = orig, orig_rb
+        awm.ops.set_resblock_one_launch(True)
     if awm.ops.conv_bf16x6():
-        # under no_grad the block IS two launches, the second with BN2 + residual + ReLU in its epilogue (epi 4), although
-        # ctx.needs_input_grad reports the trainable parameters; with the tape recording, epi 4 is never used
-        assert fused_calls == [0, 4], fused_calls
-        assert unfused_calls == [0, 0], unfused_calls
-    if awm.ops.conv_bf16x6():
-        assert torch.equal(y_fused, y_unfused.detach()), float((y_fused - y_unfused.detach()).abs().max())
+        # under no_grad the fast path is taken although ctx.needs_input_grad reports the trainable parameters; with the tape
+        # recording neither fused form is used
+        if one_launch:
+            assert fused_whole == [(B, T)] and fused_calls == [], (fused_whole, fused_calls)
+        else:
+            assert fused_calls == [0, 4] and fused_whole == [], (fused_calls, fused_whole)
+        assert unfused_calls == [0, 0] and unfused_whole == [], (unfused_calls, unfused_whole)
+        if one_launch:      # BN1 folded into one FMA on the accumulator instead of bias-add then FMA: last-bit differences only
+            check_elementwise(y_fused, y_unfused.detach().cpu(), "one-launch vs three-launch eval resblock", rtol=1e-5, atol_of_max=2e-6)
+        else:
+            assert torch.equal(y_fused, y_unfused.detach()), float((y_fused - y_unfused.detach()).abs().max())
     yr = O.resblock({k: v.clone() for k, v in sd.items()}, "", x, False, {})
     check(y_fused, yr, FWD_TOL, "fused eval resblock")
     check_elementwise(y_fused, yr, "fused eval resblock (element-wise)")
