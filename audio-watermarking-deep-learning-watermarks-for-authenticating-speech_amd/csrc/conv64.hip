@@ -1162,7 +1162,7 @@ int launch_conv64bf3(const Conv64Args& a, hipStream_t stream) {
 // ---------------------------------------------------------------------------------------------
 struct RbeArgs {
     const float* x;       // [B,64,T]
-    const void* w1;       // packed bf16 image [3 pieces][3 taps][64 out][64 in] (wm_pack_w64_bf, mode 0)
+    const void* w1;       // packed bf16 image [3 pieces][3 taps][64 out][64 in] of w * sc[out] (wm_pack_w64_bf_scaled)
     const void* w2;
     const float* b1; const float* sc1; const float* sh1;     // conv bias, folded BN scale / shift
     const float* b2; const float* sc2; const float* sh2;
@@ -1176,7 +1176,7 @@ __global__ __launch_bounds__(256) void resblock_eval_kernel(RbeArgs a) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     unsigned short* Xb = reinterpret_cast<unsigned short*>(smem_raw);              // x window: row r = time w0 + r
     unsigned short* Ab = Xb + XBUF;                                                // a1: row j = time w0 + 1 + j
-    float* Cs = reinterpret_cast<float*>(Ab + XBUF);                               // [4][64]: k1a k1b k2a k2b
+    float* Cs = reinterpret_cast<float*>(Ab + XBUF);                               // [2][64]: k1 k2 (offsets; the scales ride in the weights)
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int mt = wave & 1, nh = wave >> 1;
@@ -1225,11 +1225,8 @@ __global__ __launch_bounds__(256) void resblock_eval_kernel(RbeArgs a) {
 #pragma unroll
     for (int i = 0; i < NC; ++i) load_combo(tile, i);
     if (tid < 64) {
-        const float s1 = a.sc1[tid], s2 = a.sc2[tid];
-        Cs[tid] = s1;
-        Cs[64 + tid] = fmaf(a.b1 ? a.b1[tid] : 0.f, s1, a.sh1[tid]);
-        Cs[128 + tid] = s2;
-        Cs[192 + tid] = fmaf(a.b2 ? a.b2[tid] : 0.f, s2, a.sh2[tid]);
+        Cs[tid] = fmaf(a.b1 ? a.b1[tid] : 0.f, a.sc1[tid], a.sh1[tid]);
+        Cs[64 + tid] = fmaf(a.b2 ? a.b2[tid] : 0.f, a.sc2[tid], a.sh2[tid]);
     }
     // rows 128, 129 of both images are read by the discarded MFMA columns only: keep them finite (zero)
     for (int i = tid; i < NP * 2 * (PITCH / 2); i += 256) {
@@ -1243,166 +1240,200 @@ __global__ __launch_bounds__(256) void resblock_eval_kernel(RbeArgs a) {
 #pragma unroll
         for (int u = 0; u < 16; ++u) split_unit(w0, u >> 2, u & 3);
     }
-    {
-        const int nx = min(tile + tstep, ntiles - 1);
-#pragma unroll
-        for (int i = 0; i < NC; ++i) load_combo(nx, i);
-    }
     __syncthreads();
+    // per-lane epilogue offsets: the 16 channels of this lane's accumulator rows (the same for both column blocks)
+    float k1[16], k2[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int co = 32 * mt + mfma_row(r, half);
+        k1[r] = Cs[co]; k2[r] = Cs[64 + co];
+    }
 
     float e1r[32];
+#ifdef WM_STAMP
+    unsigned long long tm[6] = {0, 0, 0, 0, 0, 0};
+#endif
+    unsigned* const X32 = reinterpret_cast<unsigned*>(Xb);
+    unsigned* const A32 = reinterpret_cast<unsigned*>(Ab);
+
+    // One k-step of a matrix phase: the fragment reads of the NEXT step, then the six piece products with one slice of side
+    // work (f0..f5: a handful of VALU / LDS / global instructions) pinned behind each of them.  The six MFMAs of a step
+    // chain on one accumulator, so each waits 8 passes for its predecessor: the slice between two of them is free.  The
+    // order is fixed by hand (sched_barrier fences): the group-barrier pattern conv64bf3 uses is not honoured here (the
+    // weight fragments of two convolutions overflow into AGPRs and their copies break the pattern; the side work then lands
+    // in one lump in front of six back-to-back MFMAs).
+#define FENCE __builtin_amdgcn_sched_barrier(0)
+    auto nop = []() {};
+    auto kstep = [&](const bf16x8 (&W)[12][NP], const unsigned short* img, f32x16& ac, bf16x8 (&Bq)[2][NP], int nt, int s,
+                     auto&& f0, auto&& f1, auto&& f2, auto&& f3, auto&& f4, auto&& f5) __attribute__((always_inline)) {
+        if (s + 1 < 12) {
+#pragma unroll
+            for (int p = 0; p < NP; ++p)
+                Bq[(s + 1) & 1][p] = *reinterpret_cast<const bf16x8*>(img + (p * ROWS + 32 * nt + ((s + 1) >> 2)) * PITCH + 16 * ((s + 1) & 3));
+        }
+        const bf16x8* Bf = Bq[s & 1];
+        FENCE;
+        ac = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[s][1], Bf[1], ac, 0, 0, 0); FENCE; f0(); FENCE;
+        ac = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[s][0], Bf[2], ac, 0, 0, 0); FENCE; f1(); FENCE;
+        ac = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[s][2], Bf[0], ac, 0, 0, 0); FENCE; f2(); FENCE;
+        ac = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[s][0], Bf[1], ac, 0, 0, 0); FENCE; f3(); FENCE;
+        ac = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[s][1], Bf[0], ac, 0, 0, 0); FENCE; f4(); FENCE;
+        ac = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[s][0], Bf[0], ac, 0, 0, 0); FENCE; f5(); FENCE;
+    };
+    // the bf16x3 split of a value pair in three stages (one slice each)
+    float sva = 0.f, svb = 0.f;
+    unsigned sp0 = 0, sp1 = 0, sp2 = 0;
+    auto st1 = [&]() {
+        const bf16x2 h = {(__bf16)sva, (__bf16)svb};
+        sp0 = __builtin_bit_cast(unsigned, h);
+        sva -= __uint_as_float(sp0 << 16); svb -= __uint_as_float(sp0 & 0xffff0000u);
+        asm volatile("" : "+v"(sva), "+v"(svb), "+v"(sp0));      // pins the stage into its slice (pure arithmetic sinks to its use otherwise)
+    };
+    auto st2 = [&]() {
+        const bf16x2 m = {(__bf16)sva, (__bf16)svb};
+        sp1 = __builtin_bit_cast(unsigned, m);
+        sva -= __uint_as_float(sp1 << 16); svb -= __uint_as_float(sp1 & 0xffff0000u);
+        asm volatile("" : "+v"(sva), "+v"(svb), "+v"(sp1));
+    };
+    auto st3 = [&](unsigned* img32, int o) {
+        const bf16x2 l = {(__bf16)sva, (__bf16)svb};
+        sp2 = __builtin_bit_cast(unsigned, l);
+        img32[o] = sp0; img32[(ROWS * PITCH >> 1) + o] = sp1; img32[2 * (ROWS * PITCH >> 1) + o] = sp2;
+    };
 
     while (tile < ntiles) {
-        const int next = min(tile + tstep, ntiles - 1), next2 = min(tile + 2 * tstep, ntiles - 1);
+        const int next = min(tile + tstep, ntiles - 1);
         const int b = tile / tilesPerClip, w0 = (tile - b * tilesPerClip) * NTO - 4, o0 = w0 + 2;
         const int nw0 = (next % tilesPerClip) * NTO - 4;
-        // output column of accumulator block nt of this lane, and its clamped time (residual loads)
-        int tcl[2];
-        bool okv[2];
+        // output column of accumulator block nt of this lane: byte offset inside a channel row, 0xffffffff (dropped by the
+        // buffer unit / read as 0) when the column is not an output of this tile; in1[nt]: the a1 column lies inside the clip
+        unsigned tcl[2];
+        bool in1[2];
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
-            const int i = 64 * nh + 32 * nt + l31, t = o0 + i;
-            okv[nt] = (i < NTO) && (t >= 0) && (t < T);
-            tcl[nt] = min(max(t, 0), T - 1) + 4 * half * T;
+            const int i = 64 * nh + 32 * nt + l31, t = o0 + i, u = w0 + 1 + i;
+            const bool ok = (i < NTO) && (t >= 0) && (t < T);
+            tcl[nt] = ok ? (unsigned)(t + 4 * half * T) * 4u : 0xffffffffu;
+            in1[nt] = (u >= 0) && (u < T);
         }
-        auto rowbase = [&](int r) { return ((size_t)b * 64 + 32 * mt + (r & 3) + 8 * (r >> 2)) * T; };   // wave-uniform
+        // this wave's 32 channel rows of clip b, as buffer descriptors (scalar); row r sits at the scalar offset roff(r)
+        const size_t slab = ((size_t)b * 64 + 32 * mt) * T;
+        const wm_srd_t sxr = make_srd(a.x + slab, (size_t)32 * T * sizeof(float));
+        const wm_srd_t syr = make_srd(a.y + slab, (size_t)32 * T * sizeof(float));
+        auto roff = [&](int r) { return (unsigned)(((r & 3) + 8 * (r >> 2)) * T) * 4u; };                  // wave-uniform
+        auto e1_load = [&](int idx) { e1r[idx] = buf_load(sxr, tcl[idx >> 4], roff(idx & 15)); };
+        // epilogue 1 of accumulator pair pi (rows 2 pi, 2 pi + 1 = two adjacent channels) of block nt, in slices:
+        // BN1 offset + ReLU + zero padding -> split stages -> a1 image
+        auto e1_act = [&](const f32x16& ac, int nt, int pi) {
+            const float v0 = fmaxf(ac[2 * pi] + k1[2 * pi], 0.f), v1 = fmaxf(ac[2 * pi + 1] + k1[2 * pi + 1], 0.f);
+            sva = in1[nt] ? v0 : 0.f; svb = in1[nt] ? v1 : 0.f;
+            asm volatile("" : "+v"(sva), "+v"(svb));
+        };
+        auto e1_out = [&](int nt, int pi) {
+            const int j = 64 * nh + 32 * nt + l31, co = 32 * mt + mfma_row(2 * pi, half);
+            st3(A32, (j * PITCH + co) >> 1);
+        };
+        // split of unit (combo i, element e) of the next tile's x window, in slices
+        auto x_pick = [&](int i, int e) {
+            const int t = nw0 + 4 * (q0 + 8 * i);
+            const bool ok = (t >= 0) && (t < T);
+            const float4 fa = sa[i], fb = sb[i];
+            const float va = (e == 0) ? fa.x : (e == 1) ? fa.y : (e == 2) ? fa.z : fa.w;
+            const float vb = (e == 0) ? fb.x : (e == 1) ? fb.y : (e == 2) ? fb.z : fb.w;
+            sva = ok ? va : 0.f; svb = ok ? vb : 0.f;
+            asm volatile("" : "+v"(sva), "+v"(svb));
+        };
+        auto x_out = [&](int i, int e) { st3(X32, (4 * (q0 + 8 * i) + e) * (PITCH / 2) + cp); };
+        // epilogue 2 of accumulator row r of block nt: BN2 offset + residual + ReLU + store
+        auto e2_value = [&](const f32x16& ac, int nt, int r) {
+            const float v = fmaxf(e1r[nt * 16 + r] + (ac[r] + k2[r]), 0.f);
+            buf_store(syr, v, tcl[nt], roff(r));
+        };
 
-        // ---------------- conv1 from the x image (side work: residual operand loads)
         f32x16 acc[2];
+        bf16x8 Bq[2][NP];
+        STAMP(ts0);
+        // ---------------- conv1 from the x image
+        const unsigned short* xrow = Xb + (64 * nh + l31) * PITCH + 8 * half;
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
+        for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
-        {
-            const unsigned short* xrow = Xb + (64 * nh + l31) * PITCH + 8 * half;
-            bf16x8 Bq[2][NP];
+        for (int p = 0; p < NP; ++p) Bq[0][p] = *reinterpret_cast<const bf16x8*>(xrow + p * ROWS * PITCH);
+        // column block 0; side work: fetch the next tile's x window (split during conv2)
 #pragma unroll
-            for (int p = 0; p < NP; ++p) Bq[0][p] = *reinterpret_cast<const bf16x8*>(xrow + p * ROWS * PITCH);
-#pragma unroll
-            for (int h = 0; h < 24; ++h) {
-                const int s = h >> 1, nt = h & 1;
-                if (h + 1 < 24) {
-                    const int s1_ = (h + 1) >> 1, n1 = (h + 1) & 1;
-#pragma unroll
-                    for (int p = 0; p < NP; ++p)
-                        Bq[(h + 1) & 1][p] = *reinterpret_cast<const bf16x8*>(xrow + (p * ROWS + 32 * n1 + (s1_ >> 2)) * PITCH + 16 * (s1_ & 3));
-                }
-                const bf16x8* Bf = Bq[h & 1];
-                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W1[s][1], Bf[1], acc[nt], 0, 0, 0);
-                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W1[s][0], Bf[2], acc[nt], 0, 0, 0);
-                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W1[s][2], Bf[0], acc[nt], 0, 0, 0);
-                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W1[s][0], Bf[1], acc[nt], 0, 0, 0);
-                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W1[s][1], Bf[0], acc[nt], 0, 0, 0);
-                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W1[s][0], Bf[0], acc[nt], 0, 0, 0);
-                if (h < 16) {
-                    e1r[2 * h] = (a.x + rowbase((2 * h) & 15))[tcl[(2 * h) >> 4]];
-                    e1r[2 * h + 1] = (a.x + rowbase((2 * h + 1) & 15))[tcl[(2 * h + 1) >> 4]];
-                }
-                __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
-#pragma unroll
-                for (int kk = 0; kk < 6; ++kk) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
+        for (int s = 0; s < 12; ++s) {
+            if (s < 4) kstep(W1, xrow, acc[0], Bq, 0, s, [&]() { load_combo(next, s); }, nop, nop, nop, nop, nop);
+            else kstep(W1, xrow, acc[0], Bq, 0, s, nop, nop, nop, nop, nop, nop);
         }
-        // ---------------- epilogue 1: BN1 + ReLU, zero outside the clip, split, a1 image
-        {
-            unsigned* A32 = reinterpret_cast<unsigned*>(Ab);
+        STAMP(ts1);
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-                const int j = 64 * nh + 32 * nt + l31, u = w0 + 1 + j;
-                const bool in = (u >= 0) && (u < T);
+        for (int p = 0; p < NP; ++p) Bq[0][p] = *reinterpret_cast<const bf16x8*>(xrow + (p * ROWS + 32) * PITCH);
+        // column block 1; side work: epilogue 1 of block 0
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int c4 = 32 * mt + 8 * g + 4 * half;           // the lane's four consecutive channels of row group g
-                    const float4 ka = *reinterpret_cast<const float4*>(Cs + c4), kb = *reinterpret_cast<const float4*>(Cs + 64 + c4);
-                    const float kav[4] = {ka.x, ka.y, ka.z, ka.w}, kbv[4] = {kb.x, kb.y, kb.z, kb.w};
-                    float v[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float z = fmaxf(fmaf(acc[nt][4 * g + e], kav[e], kbv[e]), 0.f);
-                        v[e] = in ? z : 0.f;
-                    }
-                    unsigned pa0, pa1, pa2, pb0, pb1, pb2;
-                    split3_pair(v[0], v[1], pa0, pa1, pa2);
-                    split3_pair(v[2], v[3], pb0, pb1, pb2);
-                    const int o = (j * PITCH + 32 * mt + 8 * g + 4 * half) >> 1;
-                    *reinterpret_cast<uint2*>(A32 + o) = make_uint2(pa0, pb0);
-                    *reinterpret_cast<uint2*>(A32 + (ROWS * PITCH >> 1) + o) = make_uint2(pa1, pb1);
-                    *reinterpret_cast<uint2*>(A32 + 2 * (ROWS * PITCH >> 1) + o) = make_uint2(pa2, pb2);
-                }
-            }
+        for (int s = 0; s < 12; ++s) {
+            if (s < 8)
+                kstep(W1, xrow, acc[1], Bq, 1, s, [&]() { e1_act(acc[0], 0, s); }, st1, st2, [&]() { e1_out(0, s); }, nop, nop);
+            else kstep(W1, xrow, acc[1], Bq, 1, s, nop, nop, nop, nop, nop, nop);
         }
+        // epilogue 1 of block 1 (serial)
+        STAMP(ts2);
+#pragma unroll
+        for (int pi = 0; pi < 8; ++pi) { e1_act(acc[1], 1, pi); st1(); st2(); e1_out(1, pi); }
+        STAMP(ts3);
         lds_barrier();          // a1 image complete; every wave is done with the x image
-        // ---------------- conv2 from the a1 image (side work: split the next tile's x window, fetch the one after)
+        STAMP(ts4);
+        // ---------------- conv2 from the a1 image
+        const unsigned short* arow = Ab + (64 * nh + l31) * PITCH + 8 * half;
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
+        for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
-        {
-            const unsigned short* xrow = Ab + (64 * nh + l31) * PITCH + 8 * half;
-            bf16x8 Bq[2][NP];
+        for (int p = 0; p < NP; ++p) Bq[0][p] = *reinterpret_cast<const bf16x8*>(arow + p * ROWS * PITCH);
+        // column block 0; side work: first half of the next tile's x window, residual operand of block 0
 #pragma unroll
-            for (int p = 0; p < NP; ++p) Bq[0][p] = *reinterpret_cast<const bf16x8*>(xrow + p * ROWS * PITCH);
-#pragma unroll
-            for (int h = 0; h < 24; ++h) {
-                const int s = h >> 1, nt = h & 1;
-                if (h + 1 < 24) {
-                    const int s1_ = (h + 1) >> 1, n1 = (h + 1) & 1;
-#pragma unroll
-                    for (int p = 0; p < NP; ++p)
-                        Bq[(h + 1) & 1][p] = *reinterpret_cast<const bf16x8*>(xrow + (p * ROWS + 32 * n1 + (s1_ >> 2)) * PITCH + 16 * (s1_ & 3));
-                }
-                const bf16x8* Bf = Bq[h & 1];
-                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W2[s][1], Bf[1], acc[nt], 0, 0, 0);
-                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W2[s][0], Bf[2], acc[nt], 0, 0, 0);
-                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W2[s][2], Bf[0], acc[nt], 0, 0, 0);
-                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W2[s][0], Bf[1], acc[nt], 0, 0, 0);
-                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W2[s][1], Bf[0], acc[nt], 0, 0, 0);
-                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W2[s][0], Bf[0], acc[nt], 0, 0, 0);
-                if (h < 16) {
-                    split_unit(nw0, h >> 2, h & 3);
-                    if ((h & 3) == 3) load_combo(next2, h >> 2);       // this combo's registers are free again
-                }
-                __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
-#pragma unroll
-                for (int kk = 0; kk < 6; ++kk) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
+        for (int s = 0; s < 12; ++s) {
+            if (s < 8)
+                kstep(W2, arow, acc[0], Bq, 0, s, [&]() { x_pick(s >> 2, s & 3); }, st1, st2, [&]() { x_out(s >> 2, s & 3); },
+                      [&]() { e1_load(2 * s); }, [&]() { e1_load(2 * s + 1); });
+            else kstep(W2, arow, acc[0], Bq, 0, s, nop, nop, nop, nop, nop, nop);
         }
-        // ---------------- epilogue 2: BN2 + residual + ReLU, store
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-            if (okv[nt]) {
+        for (int p = 0; p < NP; ++p) Bq[0][p] = *reinterpret_cast<const bf16x8*>(arow + (p * ROWS + 32) * PITCH);
+        // column block 1; side work: second half of the window, residual operand of block 1, epilogue 2 of block 0
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int c4 = 32 * mt + 8 * g + 4 * half;
-                    const float4 ka = *reinterpret_cast<const float4*>(Cs + 128 + c4), kb = *reinterpret_cast<const float4*>(Cs + 192 + c4);
-                    const float kav[4] = {ka.x, ka.y, ka.z, ka.w}, kbv[4] = {kb.x, kb.y, kb.z, kb.w};
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int r = 4 * g + e;
-                        const float v = fmaxf(e1r[nt * 16 + r] + fmaf(acc[nt][r], kav[e], kbv[e]), 0.f);
-                        (a.y + rowbase(r))[tcl[nt]] = v;
-                    }
-                }
-            }
+        for (int s = 0; s < 12; ++s) {
+            if (s < 4)
+                kstep(W2, arow, acc[1], Bq, 1, s, [&]() { x_pick(2 + (s >> 2), s & 3); }, st1, st2, [&]() { x_out(2 + (s >> 2), s & 3); },
+                      [&]() { e1_load(16 + 4 * s); e1_load(17 + 4 * s); }, [&]() { e1_load(18 + 4 * s); e1_load(19 + 4 * s); });
+            else if (s < 8)
+                kstep(W2, arow, acc[1], Bq, 1, s, [&]() { x_pick(2 + (s >> 2), s & 3); }, st1, st2, [&]() { x_out(2 + (s >> 2), s & 3); },
+                      [&]() { e2_value(acc[0], 0, 2 * (s - 4)); }, [&]() { e2_value(acc[0], 0, 2 * (s - 4) + 1); });
+            else
+                kstep(W2, arow, acc[1], Bq, 1, s, nop, nop, nop, nop,
+                      [&]() { e2_value(acc[0], 0, 2 * (s - 4)); }, [&]() { e2_value(acc[0], 0, 2 * (s - 4) + 1); });
         }
+        // epilogue 2 of block 1 (serial)
+        STAMP(ts5);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) e2_value(acc[1], 1, r);
         lds_barrier();          // next x image complete; a1 image free
+        STAMP(ts6);
+#ifdef WM_STAMP
+        tm[0] += ts1 - ts0; tm[1] += ts2 - ts1; tm[2] += ts3 - ts2; tm[3] += ts4 - ts3; tm[4] += ts5 - ts4; tm[5] += ts6 - ts5;
+#endif
         tile += tstep;
     }
+#undef FENCE
+#ifdef WM_STAMP
+    if (g_wm_stamp && lane == 0) {
+        unsigned long long* d = g_wm_stamp + ((size_t)blockIdx.x * 4 + wave) * 6;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) d[i] = tm[i];
+    }
+#endif
 }
 
 static int launch_resblock_eval(const RbeArgs& a, hipStream_t stream) {
-    constexpr size_t lds = (size_t)(2 * 3 * 130 * 72) * 2 + 4 * 64 * sizeof(float);
+    constexpr size_t lds = (size_t)(2 * 3 * 130 * 72) * 2 + 2 * 64 * sizeof(float);
     static wm::DevOnce attr_done;
     if (!wm::dev_done(attr_done)) {
         WM_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(resblock_eval_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1815,11 +1846,13 @@ __global__ void pack_w64_bf7_kernel(const float* __restrict__ w, unsigned short*
 }
 
 // bf16 three-piece weight image [piece][tap][out][in] (uint16) for the k3 convolutions; mode as wm_pack_w64 (0 / 1)
-__global__ void pack_w64_bf_kernel(const float* __restrict__ w, unsigned short* __restrict__ wpb, int mode) {
+__global__ void pack_w64_bf_kernel(const float* __restrict__ w, const float* __restrict__ row_scale,
+                                   unsigned short* __restrict__ wpb, int mode) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= 3 * 4096) return;
     const int tap = i / 4096, out = (i / 64) % 64, in = i % 64;
-    const float v = (mode == 0) ? w[(out * 64 + in) * 3 + tap] : w[(in * 64 + out) * 3 + (2 - tap)];
+    float v = (mode == 0) ? w[(out * 64 + in) * 3 + tap] : w[(in * 64 + out) * 3 + (2 - tap)];
+    if (row_scale) v *= row_scale[out];          // a per-output-channel factor (folded BatchNorm scale) rides in the weights
     unsigned p0, p1, p2;
     split3_pair(v, 0.f, p0, p1, p2);
     wpb[i] = (unsigned short)p0; wpb[3 * 4096 + i] = (unsigned short)p1; wpb[2 * 3 * 4096 + i] = (unsigned short)p2;
@@ -2450,7 +2483,14 @@ int wm_conv64(const float* x, const float* x2, const float* wp, const float* pa,
 // Same pro / epi / stats contract as wm_conv64 with KW = 3.
 int wm_pack_w64_bf(const float* w, void* wpb, int mode, hipStream_t stream) {
     if (mode < 0 || mode > 1) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(pack_w64_bf_kernel, dim3(48), dim3(256), 0, stream, w, reinterpret_cast<unsigned short*>(wpb), mode);
+    hipLaunchKernelGGL(pack_w64_bf_kernel, dim3(48), dim3(256), 0, stream, w, (const float*)nullptr, reinterpret_cast<unsigned short*>(wpb), mode);
+    WM_CHECK_LAUNCH();
+    return 0;
+}
+// forward image (mode 0) of w[out][in][k] * row_scale[out]
+int wm_pack_w64_bf_scaled(const float* w, const float* row_scale, void* wpb, hipStream_t stream) {
+    if (!w || !row_scale || !wpb) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(pack_w64_bf_kernel, dim3(48), dim3(256), 0, stream, w, row_scale, reinterpret_cast<unsigned short*>(wpb), 0);
     WM_CHECK_LAUNCH();
     return 0;
 }

@@ -38,24 +38,6 @@ struct GConvArgs {
 constexpr int kr_max_of(int bm) { return bm >= 128 ? 36 : 48; }
 constexpr int xr_of(int bn) { return bn >= 256 ? 16 : 10; }   // input-tile elements a thread stages per chunk, by tile width
 
-typedef __amdgpu_buffer_rsrc_t wm_srd_t;   // 128-bit buffer resource descriptor (kept in scalar registers)
-
-// buffer descriptor over [p, p + bytes): 32-bit per-lane byte offsets + a scalar offset, reads past the end return 0
-__device__ __forceinline__ wm_srd_t make_srd(const float* p, size_t bytes) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), (short)0, (int)(bytes > 0xfffff000ull ? 0xfffff000ull : bytes),
-                                             0x00020000);
-}
-__device__ __forceinline__ float buf_load(wm_srd_t srd, unsigned voff_bytes, unsigned soff_bytes) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd, (int)voff_bytes, (int)soff_bytes, 0));
-}
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ f32x4 buf_load4(wm_srd_t srd, unsigned voff_bytes, unsigned soff_bytes) {
-    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd, (int)voff_bytes, (int)soff_bytes, 0));
-}
-__device__ __forceinline__ void buf_store(wm_srd_t srd, float v, unsigned voff_bytes, unsigned soff_bytes) {
-    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), srd, (int)voff_bytes, (int)soff_bytes, 0);
-}
-
 // Implicit-GEMM tile kernel.  Workgroup = 4 waves as MW x (4/MW); a wave owns WM x WN blocks of 32 x 32 (fp32 MFMA
 // 32x32x2, the two k of an instruction = the two channels of a pair at one tap).  Per chunk of CI input channels the
 // workgroup stages the input rows [CI][XW] (dword loads, coalesced along time, any alignment) and the weight rows

@@ -155,4 +155,23 @@ __device__ __forceinline__ f32x16 mfma_bf16x6(const bf16x8 (&A)[3], const bf16x8
     return acc;
 }
 
+// ---- buffer addressing (scalar descriptor + 32-bit per-lane byte offset + scalar offset; out-of-range lanes read 0 / are dropped)
+typedef __amdgpu_buffer_rsrc_t wm_srd_t;   // 128-bit buffer resource descriptor (kept in scalar registers)
+
+// buffer descriptor over [p, p + bytes): 32-bit per-lane byte offsets + a scalar offset, reads past the end return 0
+__device__ __forceinline__ wm_srd_t make_srd(const float* p, size_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), (short)0, (int)(bytes > 0xfffff000ull ? 0xfffff000ull : bytes),
+                                             0x00020000);
+}
+__device__ __forceinline__ float buf_load(wm_srd_t srd, unsigned voff_bytes, unsigned soff_bytes) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd, (int)voff_bytes, (int)soff_bytes, 0));
+}
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 buf_load4(wm_srd_t srd, unsigned voff_bytes, unsigned soff_bytes) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd, (int)voff_bytes, (int)soff_bytes, 0));
+}
+__device__ __forceinline__ void buf_store(wm_srd_t srd, float v, unsigned voff_bytes, unsigned soff_bytes) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), srd, (int)voff_bytes, (int)soff_bytes, 0);
+}
+
 }  // namespace wm

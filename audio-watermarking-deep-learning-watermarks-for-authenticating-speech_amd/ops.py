@@ -227,7 +227,10 @@ class ResBlockFn(GradAwareFunction):
             lib.wm_bn_eval_scale_shift(_p(g2), _p(be2), _p(rm2), _p(rv2), BN_EPS, _p(sc2), _p(sh2), st)
             if not wants_grad(ctx) and _CONV["bf16x6"] and _CONV["one_launch_eval"]:
                 # inference: the whole block is ONE launch -- x in, out out, the intermediate activation stays in LDS
-                wp1, wp2 = pack_w64_bf(w1, 0), pack_w64_bf(w2, 0)       # both images must be alive at the launch
+                wp1 = torch.empty(3 * 3 * 4096, dtype=torch.int16, device=dev)          # both images must be alive at the launch
+                wp2 = torch.empty_like(wp1)
+                lib.wm_pack_w64_bf_scaled(_p(w1), _p(sc1), _p(wp1), st)
+                lib.wm_pack_w64_bf_scaled(_p(w2), _p(sc2), _p(wp2), st)
                 lib.wm_resblock_eval_bf(_p(x), _p(wp1), _p(wp2), _p(b1), _p(sc1), _p(sh1), _p(b2), _p(sc2), _p(sh2), _p(out), B, T, st)
                 return out
             y1 = torch.empty_like(x)

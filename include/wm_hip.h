@@ -68,8 +68,10 @@ int wm_conv64_bf(const float* x, const float* x2, const void* wpb, const float* 
 
 /* Inference ResBlock as ONE launch (py/main16.py:112-125 with both BatchNorm1d in eval mode):
  *   y = relu(x + (conv2(relu((conv1(x) + b1) * sc1 + sh1)) + b2) * sc2 + sh2)
- * sc / sh = the folded running statistics (wm_bn_eval_scale_shift), w1pb / w2pb = wm_pack_w64_bf mode-0 images, b1 / b2 may be
- * NULL.  Two frame passes over HBM (x in, y out): the intermediate activation stays in LDS as bf16x3 pieces.  T % 4 == 0. */
+ * sc / sh = the folded running statistics (wm_bn_eval_scale_shift); w1pb / w2pb = wm_pack_w64_bf_scaled images of
+ * w1 * sc1[out] / w2 * sc2[out] (the per-channel scale rides in the weights, the kernel adds b * sc + sh); b1 / b2 may be NULL.
+ * Two frame passes over HBM (x in, y out): the intermediate activation stays in LDS as bf16x3 pieces.  T % 4 == 0. */
+int wm_pack_w64_bf_scaled(const float* w, const float* row_scale, void* wpb, wm_stream_t stream);
 int wm_resblock_eval_bf(const float* x, const void* w1pb, const void* w2pb, const float* b1, const float* sc1, const float* sh1,
                         const float* b2, const float* sc2, const float* sh2, float* y, int B, int T, wm_stream_t stream);
 
