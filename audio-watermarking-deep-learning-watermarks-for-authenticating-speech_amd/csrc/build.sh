@@ -3,7 +3,9 @@
 set -euo pipefail
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result"
+# -pragma-unroll-threshold: the hand-scheduled MFMA loops (conv64bf3, resblock_eval) must unroll completely; above the default
+# 16K-instruction limit the compiler silently unrolls by 2 and the register-resident weight fragments land in scratch memory
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result -mllvm -pragma-unroll-threshold=100000 ${WM_EXTRA_FLAGS:-}"
 mkdir -p obj
 pids=()
 for f in conv64 bn small_convs lstm postproc stft_loss losses gconv; do

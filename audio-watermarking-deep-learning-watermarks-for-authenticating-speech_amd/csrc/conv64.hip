@@ -844,6 +844,9 @@ int launch_conv64bf(const Conv64Args& a, hipStream_t stream) {
 #ifndef WM_NT_STORE
 #define WM_NT_STORE 0
 #endif
+#ifndef WM_BF3_MANUAL
+#define WM_BF3_MANUAL 1
+#endif
 // XCD-aware workgroup -> tile-slot map.  Workgroups are dealt round-robin to the 8 XCDs (blockIdx % 8), each with its
 // own L2.  Giving XCD x the 1/8 of the tile sequence [x*G/8, (x+1)*G/8) makes time-adjacent tiles share an L2, so the
 // halo columns (a 128-B line per channel per side, +50 % fetched bytes otherwise) and the neighbours' lines hit in L2.
@@ -964,6 +967,58 @@ __global__ __launch_bounds__(256) void conv64bf3_kernel(Conv64Args a) {
             X[o] = (unsigned short)p0; X[ROWS * PITCH + o] = (unsigned short)p1; X[2 * ROWS * PITCH + o] = (unsigned short)p2;
         }
     };
+    // the same split in stages, one per scheduling slice of the main loop (WM_BF3_MANUAL)
+    float sva = 0.f, svb = 0.f;
+    unsigned sp0 = 0, sp1 = 0;
+    auto split_pick = [&](int i, int e) {
+        const float4 fa = sa[i], fb = sb[i];
+        float va = (e == 0) ? fa.x : (e == 1) ? fa.y : (e == 2) ? fa.z : fa.w;
+        float vb = (e == 0) ? fb.x : (e == 1) ? fb.y : (e == 2) ? fb.z : fb.w;
+        if (PRO != PRO_NONE) {
+            float wa = 0.f, wb = 0.f;
+            if (TWO) {
+                const float4 ga = sa2[i], gb = sb2[i];
+                wa = (e == 0) ? ga.x : (e == 1) ? ga.y : (e == 2) ? ga.z : ga.w;
+                wb = (e == 0) ? gb.x : (e == 1) ? gb.y : (e == 2) ? gb.z : gb.w;
+            }
+            va = pro_apply<PRO>(va, wa, ka0, kb0, kc0, kl0);
+            vb = pro_apply<PRO>(vb, wb, ka1, kb1, kc1, kl1);
+        }
+        sva = va; svb = vb;
+        asm volatile("" : "+v"(sva), "+v"(svb));
+    };
+    auto split_st1 = [&]() {
+        const bf16x2 hh_ = {(__bf16)sva, (__bf16)svb};
+        sp0 = __builtin_bit_cast(unsigned, hh_);
+        sva -= __uint_as_float(sp0 << 16); svb -= __uint_as_float(sp0 & 0xffff0000u);
+        asm volatile("" : "+v"(sva), "+v"(svb), "+v"(sp0));
+    };
+    auto split_st2 = [&]() {
+        const bf16x2 mm_ = {(__bf16)sva, (__bf16)svb};
+        sp1 = __builtin_bit_cast(unsigned, mm_);
+        sva -= __uint_as_float(sp1 << 16); svb -= __uint_as_float(sp1 & 0xffff0000u);
+        asm volatile("" : "+v"(sva), "+v"(svb), "+v"(sp1));
+    };
+    auto split_out = [&](unsigned* X32, int i, int e) {
+        const bf16x2 ll_ = {(__bf16)sva, (__bf16)svb};
+        const unsigned sp2 = __builtin_bit_cast(unsigned, ll_);
+        const int o = (1 + 4 * (q0 + 8 * i) + e) * (PITCH / 2) + cp;
+        X32[o] = sp0; X32[(ROWS * PITCH >> 1) + o] = sp1; X32[2 * (ROWS * PITCH >> 1) + o] = sp2;
+    };
+    auto halo_pick = [&](int t0) {
+        const int t = hh ? t0 + NT : t0 - 1;
+        float v = hl;
+        if (PRO != PRO_NONE) v = pro_apply<PRO>(v, hl2, ha, hb, hcc, hlo);
+        if (t < 0 || t >= T) v = 0.f;
+        sva = v; svb = 0.f;
+        asm volatile("" : "+v"(sva), "+v"(svb));
+    };
+    auto halo_out = [&](unsigned short* X) {
+        const bf16x2 ll_ = {(__bf16)sva, (__bf16)svb};
+        const unsigned sp2 = __builtin_bit_cast(unsigned, ll_);
+        const int o = (hh ? NT + 1 : 0) * PITCH + hc;
+        X[o] = (unsigned short)sp0; X[ROWS * PITCH + o] = (unsigned short)sp1; X[2 * ROWS * PITCH + o] = (unsigned short)sp2;
+    };
     {
         const int t0 = (min(tile, ntiles - 1) % tilesPerClip) * NT;
 #pragma unroll
@@ -1016,6 +1071,9 @@ __global__ __launch_bounds__(256) void conv64bf3_kernel(Conv64Args a) {
         if (EPI == EPI_BNADDRELU) v = fmaxf(e1r[idx] + fmaf(v + Cs[192 + co], Cs[256 + co], Cs[320 + co]), 0.f);   // = wm_bn_add_relu of the biased conv
         (a.y + sidx(nt, r))[loff] = v;
         if (STATS) { s1[r] = fmaf(pflag, v, s1[r]); s2[r] = fmaf(pflag * v, (EPI == EPI_RELUMASK) ? q : v, s2[r]); }
+#if WM_BF3_MANUAL
+        if (STATS) asm volatile("" : "+v"(s1[r]), "+v"(s2[r]));
+#endif
         if (E1 && cb >= 0)
             e1r[idx] = (a.e1 + ((size_t)cb * 64 + 32 * mt + (r & 3) + 8 * (r >> 2)) * T + ct0 + 64 * nh + 32 * nt)[loff];
     };
@@ -1036,6 +1094,64 @@ __global__ __launch_bounds__(256) void conv64bf3_kernel(Conv64Args a) {
         bf16x8 Bq[2][NP];
 #pragma unroll
         for (int p = 0; p < NP; ++p) Bq[0][p] = *reinterpret_cast<const bf16x8*>(xrow + p * ROWS * PITCH);
+#if WM_BF3_MANUAL
+        // Hand-pinned schedule: every MFMA is followed by one slice of the side work (sched_barrier fences; the arithmetic of a
+        // slice is tied to it by an empty asm on its results).  The six MFMAs of a half-step chain on one accumulator, each
+        // waiting 8 passes for its predecessor, so a slice of <= 8 VALU instructions between two of them costs nothing.  The
+        // group-barrier pattern of the other branch leaves lumps of 30-40 instructions in front of back-to-back MFMAs.
+#define FENCE __builtin_amdgcn_sched_barrier(0)
+#define BF3_SLICE(k)                                                                                                        \
+    {                                                                                                                           \
+        if (h < 16) {                                                                                                           \
+            if ((k) == 0) split_pick(h >> 2, h & 3);                                                                            \
+            if ((k) == 1) split_st1();                                                                                          \
+            if ((k) == 2) split_st2();                                                                                          \
+            if ((k) == 3) { split_out(reinterpret_cast<unsigned*>(xnxt), h >> 2, h & 3); if ((h & 3) == 3) load_combo(next2, h >> 2); } \
+        } else if (h == 16) {                                                                                                   \
+            if ((k) == 0) halo_pick(nt0);                                                                                       \
+            if ((k) == 1) split_st1();                                                                                          \
+            if ((k) == 2) split_st2();                                                                                          \
+            if ((k) == 3) halo_out(xnxt);                                                                                       \
+        } else if (h == 17) {                                                                                                   \
+            if ((k) == 0) load_halo(next2);                                                                                     \
+        }                                                                                                                       \
+        if (h < 8) {                                                                                                            \
+            if ((k) == 4) epi_value(2 * h, b, t0);                                                                              \
+            if ((k) == 5) epi_value(2 * h + 1, b, t0);                                                                          \
+        } else if ((k) == 4) epi_value(8 + h, b, t0);                                                                           \
+    }
+#pragma unroll
+        for (int h = 0; h < 24; ++h) {
+            const int s = h >> 1, nt = h & 1;
+            if (h + 1 < 24) {
+                const int s1_ = (h + 1) >> 1, n1 = (h + 1) & 1;
+#pragma unroll
+                for (int p = 0; p < NP; ++p)
+                    Bq[(h + 1) & 1][p] = *reinterpret_cast<const bf16x8*>(xrow + (p * ROWS + 32 * n1 + (s1_ >> 2)) * PITCH + 16 * (s1_ & 3));
+            }
+            const bf16x8* Bf = Bq[h & 1];
+            FENCE;
+            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wr[s][1], Bf[1], acc[nt], 0, 0, 0); FENCE; BF3_SLICE(0) FENCE;
+            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wr[s][0], Bf[2], acc[nt], 0, 0, 0); FENCE; BF3_SLICE(1) FENCE;
+            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wr[s][2], Bf[0], acc[nt], 0, 0, 0); FENCE; BF3_SLICE(2) FENCE;
+            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wr[s][0], Bf[1], acc[nt], 0, 0, 0); FENCE; BF3_SLICE(3) FENCE;
+            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wr[s][1], Bf[0], acc[nt], 0, 0, 0); FENCE; BF3_SLICE(4) FENCE;
+            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wr[s][0], Bf[0], acc[nt], 0, 0, 0); FENCE; BF3_SLICE(5) FENCE;
+#ifdef WM_STAMP
+#ifdef WM_STAMP_FINE
+            if (h == 16) { STAMP(tsa); tm[0] += tsa - ts0; }
+            if (h == 17) { STAMP(tsb); tm[1] += tsb - ts0; }
+            if (h == 18) { STAMP(tsb); tm[3] += tsb - ts0; }
+            if (h == 20) { STAMP(tsb); tm[5] += tsb - ts0; }
+#else
+            if (h == 3) { STAMP(tsa); tm[0] += tsa - ts0; }
+            if (h == 15) { STAMP(tsb); tm[1] += tsb - ts0; }
+#endif
+#endif
+        }
+#undef FENCE
+#undef BF3_SLICE
+#else
 #pragma unroll
         for (int h = 0; h < 24; ++h) {
             const int s = h >> 1, nt = h & 1;
@@ -1083,6 +1199,7 @@ __global__ __launch_bounds__(256) void conv64bf3_kernel(Conv64Args a) {
 #endif
 #endif
         }
+#endif
         STAMP(ts1);
         accp[0] = acc[0]; accp[1] = acc[1];
         pb_ = b; pt0 = t0; pflag = 1.f;
