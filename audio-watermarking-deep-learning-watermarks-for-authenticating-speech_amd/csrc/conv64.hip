@@ -1565,227 +1565,6 @@ static int launch_resblock_eval(const RbeArgs& a, hipStream_t stream) {
 
 
 // ---------------------------------------------------------------------------------------------
-// bf16x6 convolution, two-group ("ping-pong") schedule.  The bf16 MFMA does not share the VALU pipe (the fp32 MFMA
-// does -- that is why this schedule lost with the native build), so with two waves per SIMD the split conversions,
-// LDS writes, global loads and the epilogue of one group run beside the matrix phase of the other.
-// 512 threads = 2 groups x 4 waves; each group streams its own 64-column tiles through its own LDS image (the
-// 83 KB weight image is shared); wave (mt, nt) of a group owns one 32x32 accumulator.  Groups are half a period
-// apart (one extra barrier at start-up, one at the end to balance the count).
-// ---------------------------------------------------------------------------------------------
-template <int PRO, int EPI, bool STATS>
-__global__ __launch_bounds__(512, 2) void conv64bf2_kernel(Conv64Args a) {
-    constexpr int KW = 3, NT = 64, ROWS = NT + 2, PITCH = 72, NP = 3, NC = 2;
-    constexpr bool TWO = (PRO == PRO_BNBWD);
-    constexpr bool E1 = (EPI == EPI_RELUMASK || EPI == EPI_ADD);
-    extern __shared__ __align__(16) unsigned char smem_raw[];
-    unsigned short* Wb = reinterpret_cast<unsigned short*>(smem_raw);              // [NP][KW][64 out][PITCH]
-    unsigned short* XbAll = Wb + NP * KW * 64 * PITCH;                             // [2 groups][NP][ROWS][PITCH]
-    float* Cs = reinterpret_cast<float*>(XbAll + 2 * NP * ROWS * PITCH);           // [6][64]
-    float* Red = Cs + 6 * 64;                                                      // [8 waves][2][64]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
-    const int grp = wave >> 2, wg = wave & 3, gt = tid & 255, mt = wg & 1, nt = wg >> 1;
-    unsigned short* Xb = XbAll + grp * NP * ROWS * PITCH;
-    const int T = a.T;
-    const int tilesPerClip = (T + NT - 1) / NT, ntiles = a.B * tilesPerClip;
-    const int tstride = 2 * gridDim.x, tfirst = 2 * blockIdx.x + grp;
-    const int niter = (ntiles - 2 * (int)blockIdx.x + tstride - 1) / tstride;
-
-    float4 sa[NC], sb[NC], sa2[TWO ? NC : 1], sb2[TWO ? NC : 1];
-    float hl, hl2 = 0.f;
-    auto combo = [&](int i, int& cp, int& q) {      // a wave covers 8 channel pairs x 8 time quads
-        const int idx = gt + i * 256, widx = idx >> 6, l = idx & 63;
-        cp = (widx & 3) * 8 + (l & 7);
-        q = (widx >> 2) * 8 + (l >> 3);
-    };
-    auto load_tile = [&](int tile) {
-        const int b = tile / tilesPerClip, t0 = (tile - b * tilesPerClip) * NT;
-        const float* xb = a.x + (size_t)b * 64 * T;
-        const float* xb2 = TWO ? a.x2 + (size_t)b * 64 * T : nullptr;
-#pragma unroll
-        for (int i = 0; i < NC; ++i) {
-            int cp, q;
-            combo(i, cp, q);
-            const size_t o = (size_t)(2 * cp) * T + min(t0 + 4 * q, T - 4);
-            sa[i] = *reinterpret_cast<const float4*>(xb + o);
-            sb[i] = *reinterpret_cast<const float4*>(xb + o + T);
-            if (TWO) { sa2[i] = *reinterpret_cast<const float4*>(xb2 + o); sb2[i] = *reinterpret_cast<const float4*>(xb2 + o + T); }
-        }
-        const int hc = (gt & 127) >> 1, hh = gt & 1;
-        const int ht = min(max(hh ? t0 + NT : t0 - 1, 0), T - 1);
-        hl = xb[(size_t)hc * T + ht];
-        if (TWO) hl2 = xb2[(size_t)hc * T + ht];
-    };
-    auto write_tile = [&](int tile) {
-        const int b = tile / tilesPerClip, t0 = (tile - b * tilesPerClip) * NT;
-        unsigned* X32 = reinterpret_cast<unsigned*>(Xb);
-#pragma unroll
-        for (int i = 0; i < NC; ++i) {
-            int cp, q;
-            combo(i, cp, q);
-            const int c = 2 * cp, t = t0 + 4 * q;
-            float va[4] = {sa[i].x, sa[i].y, sa[i].z, sa[i].w}, vb[4] = {sb[i].x, sb[i].y, sb[i].z, sb[i].w};
-            if (PRO != PRO_NONE) {
-                const float ca0 = (PRO == PRO_ADDVEC) ? a.pa[b * 64 + c] : Cs[c], ca1 = (PRO == PRO_ADDVEC) ? a.pa[b * 64 + c + 1] : Cs[c + 1];
-                const float cb0 = Cs[64 + c], cb1 = Cs[64 + c + 1], cc0 = Cs[128 + c], cc1 = Cs[128 + c + 1];
-                const float cl0 = TWO ? Cs[192 + c] : 0.f, cl1 = TWO ? Cs[192 + c + 1] : 0.f;
-                float wa[4] = {0.f, 0.f, 0.f, 0.f}, wb[4] = {0.f, 0.f, 0.f, 0.f};
-                if (TWO) { wa[0] = sa2[i].x; wa[1] = sa2[i].y; wa[2] = sa2[i].z; wa[3] = sa2[i].w; wb[0] = sb2[i].x; wb[1] = sb2[i].y; wb[2] = sb2[i].z; wb[3] = sb2[i].w; }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { va[e] = pro_apply<PRO>(va[e], wa[e], ca0, cb0, cc0, cl0); vb[e] = pro_apply<PRO>(vb[e], wb[e], ca1, cb1, cc1, cl1); }
-            }
-            const bool ok = t < T;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                unsigned p0, p1, p2;
-                split3_pair(ok ? va[e] : 0.f, ok ? vb[e] : 0.f, p0, p1, p2);
-                const int o = ((1 + 4 * q + e) * PITCH + c) >> 1;
-                X32[o] = p0; X32[(ROWS * PITCH >> 1) + o] = p1; X32[2 * (ROWS * PITCH >> 1) + o] = p2;
-            }
-        }
-        if (gt < 128) {
-            const int hc = gt >> 1, hh = gt & 1, t = hh ? t0 + NT : t0 - 1;
-            float v = hl;
-            if (PRO != PRO_NONE) {
-                const float ca = (PRO == PRO_ADDVEC) ? a.pa[b * 64 + hc] : Cs[hc];
-                v = pro_apply<PRO>(v, hl2, ca, Cs[64 + hc], Cs[128 + hc], TWO ? Cs[192 + hc] : 0.f);
-            }
-            if (t < 0 || t >= T) v = 0.f;
-            unsigned p0, p1, p2;
-            split3_pair(v, 0.f, p0, p1, p2);
-            const int o = (hh ? NT + 1 : 0) * PITCH + hc;
-            Xb[o] = (unsigned short)p0; Xb[ROWS * PITCH + o] = (unsigned short)p1; Xb[2 * ROWS * PITCH + o] = (unsigned short)p2;
-        }
-    };
-
-    f32x16 acc;
-    auto mfma_tile = [&]() {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        const unsigned short* wbase = Wb + (mt * 32 + l31) * PITCH + 8 * half;
-        const unsigned short* xbase = Xb + (nt * 32 + l31) * PITCH + 8 * half;
-#pragma unroll 1
-        for (int tap = 0; tap < KW; ++tap) {
-#pragma unroll
-            for (int ch = 0; ch < 4; ++ch) {
-                bf16x8 A[NP], Bf[NP];
-#pragma unroll
-                for (int p = 0; p < NP; ++p) {
-                    Bf[p] = *reinterpret_cast<const bf16x8*>(xbase + (p * ROWS + tap) * PITCH + 16 * ch);
-                    A[p] = *reinterpret_cast<const bf16x8*>(wbase + ((p * KW + tap) * 64) * PITCH + 16 * ch);
-                }
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[1], Bf[1], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0], Bf[2], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[2], Bf[0], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0], Bf[1], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[1], Bf[0], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0], Bf[0], acc, 0, 0, 0);
-            }
-        }
-    };
-    float qe[E1 ? 16 : 1];
-    auto epi_issue = [&](int tile) {
-        if constexpr (E1) {
-            const int b = tile / tilesPerClip, t0 = (tile - b * tilesPerClip) * NT;
-            const float* eb1 = a.e1 + (size_t)b * 64 * T + min(t0 + nt * 32 + l31, T - 1);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) qe[r] = eb1[(size_t)(mt * 32 + mfma_row(r, half)) * T];
-        }
-    };
-    auto epilogue = [&](int tile) {
-        const int b = tile / tilesPerClip, t0 = (tile - b * tilesPerClip) * NT;
-        const int t = t0 + nt * 32 + l31;
-        const bool ok = t < T;
-        float* yb = a.y + (size_t)b * 64 * T + t;
-        float s1v[16], s2v[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int co = mt * 32 + mfma_row(r, half);
-            float v = acc[r];
-            float qq = 0.f;
-            if constexpr (E1) qq = qe[r];
-            if (EPI == EPI_BIAS) v += Cs[192 + co];
-            if (EPI == EPI_RELUMASK) v = (fmaf(qq, Cs[256 + co], Cs[320 + co]) > 0.f) ? v : 0.f;
-            if (EPI == EPI_ADD) v += qq;
-            if (ok) yb[(size_t)co * T] = v;
-            if constexpr (STATS) {
-                s1v[r] = ok ? v : 0.f;
-                s2v[r] = ok ? ((EPI == EPI_RELUMASK) ? v * qq : v * v) : 0.f;
-            }
-        }
-        if constexpr (STATS) {
-            const float t1 = half_wave_transpose_sum16(s1v, lane);
-            const float t2 = half_wave_transpose_sum16(s2v, lane);
-            if (l31 < 16) {
-                const int co = mt * 32 + mfma_row(l31, half);
-                Red[wave * 128 + co] += t1;
-                Red[wave * 128 + 64 + co] += t2;
-            }
-        }
-    };
-
-    int cur = tfirst, nxt = tfirst + tstride;
-    if (cur < ntiles) load_tile(cur);
-    for (int i = tid; i < NP * KW * 64 * 8; i += 512) {
-        const int row = i >> 3, seg = i & 7;
-        *reinterpret_cast<uint4*>(Wb + row * PITCH + seg * 8) = reinterpret_cast<const uint4*>(a.wp)[i];
-    }
-    if (tid < 64) {
-        Cs[tid] = (PRO == PRO_BNRELU || PRO == PRO_BNBWD) ? a.pa[tid] : 0.f;
-        Cs[64 + tid] = (PRO == PRO_BNRELU || PRO == PRO_BNBWD) ? a.pb[tid] : 0.f;
-        Cs[128 + tid] = (PRO == PRO_BNBWD) ? a.pc[tid] : 0.f;
-        Cs[192 + tid] = (PRO == PRO_BNBWD) ? a.pb[64 + tid] : ((EPI == EPI_BIAS && a.bias) ? a.bias[tid] : 0.f);
-        Cs[256 + tid] = (EPI == EPI_RELUMASK) ? a.ea[tid] : 0.f;
-        Cs[320 + tid] = (EPI == EPI_RELUMASK) ? a.eb[tid] : 0.f;
-    }
-    for (int i = tid; i < 8 * 128; i += 512) Red[i] = 0.f;
-    __syncthreads();
-    if (cur < ntiles) write_tile(cur);
-    if (nxt < ntiles) load_tile(nxt);
-    __syncthreads();
-    if (grp == 1) __syncthreads();                    // half-period shift between the two groups
-    for (int it = 0; it < niter; ++it) {
-        if (cur < ntiles) mfma_tile();                // matrix phase (the other group is in its memory phase)
-        __syncthreads();
-        if (cur < ntiles) epi_issue(cur);             // memory phase
-        if (nxt < ntiles) write_tile(nxt);
-        const int nn = nxt + tstride;
-        if (nn < ntiles) load_tile(nn);
-        if (cur < ntiles) epilogue(cur);
-        cur = nxt;
-        nxt = nn;
-        __syncthreads();
-    }
-    if (grp == 0) __syncthreads();                    // balance the start-up shift
-    if (STATS) {
-        __syncthreads();
-        if (tid < 128) {
-            float sum = 0.f;
-#pragma unroll
-            for (int w = 0; w < 8; ++w) sum += Red[w * 128 + tid];
-            a.stats[(size_t)blockIdx.x * 128 + tid] = sum;
-        }
-    }
-}
-
-template <int PRO, int EPI, bool STATS>
-int launch_conv64bf2(const Conv64Args& a, hipStream_t stream) {
-    constexpr size_t lds = (size_t)(3 * 3 * 64 * 72 + 2 * 3 * 66 * 72) * 2 + (6 * 64 + 8 * 128) * sizeof(float);
-    static wm::DevOnce attr_done;
-    auto kern = conv64bf2_kernel<PRO, EPI, STATS>;
-    if (!wm::dev_done(attr_done)) {
-        WM_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        wm::dev_mark(attr_done);
-    }
-    const int ntiles = a.B * ((a.T + 63) / 64);
-    int grid = (ntiles + 1) / 2;
-    if (grid > kNumCU) grid = kNumCU;
-    if (STATS && grid < kNumCU) WM_TRY(hipMemsetAsync(a.stats, 0, sizeof(float) * 128 * kNumCU, stream));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, a);
-    WM_CHECK_LAUNCH();
-    return 0;
-}
-
-// ---------------------------------------------------------------------------------------------
 // bf16x6 build of the 7-tap convolution (Generator.decoder[0] = ConvTranspose1d(64,64,7,padding=3), py/main16.py:144,
 // forward and data gradient).  The 3-piece image of all 7 taps is 194 KB -- more than LDS -- so a workgroup keeps the
 // taps of HALF the output channels (97 KB) and the (tile, half) pairs are dealt over the grid: workgroup g owns half
@@ -2612,9 +2391,8 @@ int wm_pack_w64_bf_scaled(const float* w, const float* row_scale, void* wpb, hip
     return 0;
 }
 
-// schedule of wm_conv64_bf: 0 = one wave per SIMD (128-column tiles), 1 = two-group ping-pong (64-column tiles)
-static int g_bf_schedule = 2;   // 0: phase-serial, 1: two-group ping-pong, 2: register-resident weights + interleaved pipeline (fastest, needs T % 128 == 0)
-int wm_set_conv_bf_schedule(int schedule, hipStream_t) { g_bf_schedule = (schedule >= 0 && schedule <= 2) ? schedule : 0; return 0; }
+static int g_bf_schedule = 2;   // 0: phase-serial kernel | 2: register-resident weights + interleaved pipeline (fastest, needs T % 128 == 0)
+int wm_set_conv_bf_schedule(int schedule, hipStream_t) { g_bf_schedule = (schedule == 2) ? 2 : 0; return 0; }
 
 int wm_conv64_bf(const float* x, const float* x2, const void* wpb, const float* pa, const float* pb, const float* pc,
                  const float* bias, const float* e1, const float* ea, const float* eb, float* y, float* stats,
@@ -2636,14 +2414,6 @@ int wm_conv64_bf(const float* x, const float* x2, const void* wpb, const float* 
         if (pro == PRO_BNBWD && epi == EPI_RELUMASK && st) return launch_conv64bf3<PRO_BNBWD, EPI_RELUMASK, true>(a, stream);
         if (pro == PRO_BNBWD && epi == EPI_ADD && !st) return launch_conv64bf3<PRO_BNBWD, EPI_ADD, false>(a, stream);
         if (pro == PRO_BNBWD && epi == EPI_NONE && !st) return launch_conv64bf3<PRO_BNBWD, EPI_NONE, false>(a, stream);
-        return (int)hipErrorInvalidValue;
-    }
-    if (g_bf_schedule == 1) {
-        if (pro == PRO_NONE && epi == EPI_BIAS) return st ? launch_conv64bf2<PRO_NONE, EPI_BIAS, true>(a, stream) : launch_conv64bf2<PRO_NONE, EPI_BIAS, false>(a, stream);
-        if (pro == PRO_BNRELU && epi == EPI_BIAS) return st ? launch_conv64bf2<PRO_BNRELU, EPI_BIAS, true>(a, stream) : launch_conv64bf2<PRO_BNRELU, EPI_BIAS, false>(a, stream);
-        if (pro == PRO_BNBWD && epi == EPI_RELUMASK && st) return launch_conv64bf2<PRO_BNBWD, EPI_RELUMASK, true>(a, stream);
-        if (pro == PRO_BNBWD && epi == EPI_ADD && !st) return launch_conv64bf2<PRO_BNBWD, EPI_ADD, false>(a, stream);
-        if (pro == PRO_BNBWD && epi == EPI_NONE && !st) return launch_conv64bf2<PRO_BNBWD, EPI_NONE, false>(a, stream);
         return (int)hipErrorInvalidValue;
     }
     if (pro == PRO_NONE && epi == EPI_BIAS) return st ? launch_conv64bf<PRO_NONE, EPI_BIAS, true>(a, stream) : launch_conv64bf<PRO_NONE, EPI_BIAS, false>(a, stream);

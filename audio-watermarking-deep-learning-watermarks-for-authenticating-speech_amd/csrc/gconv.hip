@@ -342,53 +342,6 @@ __global__ void permute_acl_kernel(const float* __restrict__ x, float* __restric
     y[((size_t)l * C + c) * A + aa] = x[i];
 }
 
-// One LSTM time step for hidden size H (multiple of 32) and batch Bn, state kept time-major / unit-major:
-//   gates[q*H + u][b] = xp[q*H + u][b] + sum_k whhT[k][q*H + u] * hprev[k][b]          (MFMA, K = H)
-//   c = sig(f) c + sig(i) tanh(g);  h = sig(o) tanh(c)
-// wave = 32 units x 32 batch columns x 4 gates.  hprev == nullptr means zero initial state.
-__global__ __launch_bounds__(64) void lstm_h_step_fwd_kernel(const float* xp, const float* __restrict__ whhT,
-                                                            const float* __restrict__ hprev, const float* __restrict__ cprev,
-                                                            float* __restrict__ hout, float* __restrict__ cout,
-                                                            float* gates_out /* may alias xp */, int H, int Bn) {
-    const int lane = threadIdx.x, half = lane >> 5, l31 = lane & 31;
-    const int u0 = blockIdx.x * 32, b0 = blockIdx.y * 32;
-    const int bcol = min(b0 + l31, Bn - 1);
-    f32x16 acc[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
-    if (hprev) {
-        for (int ks = 0; ks < H / 2; ++ks) {
-            const int k = 2 * ks + half;
-            const float bv = hprev[(size_t)k * Bn + bcol];
-            const float* wr = whhT + (size_t)k * 4 * H + u0 + l31;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) acc[q] = mfma32(wr[q * H], bv, acc[q]);
-        }
-    }
-    if (b0 + l31 >= Bn) return;
-    const int b = b0 + l31;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int u = u0 + mfma_row(r, half);
-        const float ai = acc[0][r] + xp[(size_t)(0 * H + u) * Bn + b];
-        const float af = acc[1][r] + xp[(size_t)(1 * H + u) * Bn + b];
-        const float ag = acc[2][r] + xp[(size_t)(2 * H + u) * Bn + b];
-        const float ao = acc[3][r] + xp[(size_t)(3 * H + u) * Bn + b];
-        const float gi = 1.f / (1.f + expf(-ai)), gf = 1.f / (1.f + expf(-af)), gg = tanhf(ag), go = 1.f / (1.f + expf(-ao));
-        const float cp = cprev ? cprev[(size_t)u * Bn + b] : 0.f;
-        const float c = gf * cp + gi * gg;
-        const float h = go * tanhf(c);
-        hout[(size_t)u * Bn + b] = h;
-        cout[(size_t)u * Bn + b] = c;
-        if (gates_out) {
-            gates_out[(size_t)(0 * H + u) * Bn + b] = gi; gates_out[(size_t)(1 * H + u) * Bn + b] = gf;
-            gates_out[(size_t)(2 * H + u) * Bn + b] = gg; gates_out[(size_t)(3 * H + u) * Bn + b] = go;
-        }
-    }
-}
-
 // ---------------------------------------------------------------------------------------------------------------
 // Generic weight gradient as ONE plain GEMM with the taps folded into the column index:
 //     G[a][j] = sum_{nb,t} A[nb][a][t] * Bx[nb][b][t + k - P],      j = b*K + k   (= the memory order of dW[a][b][k])
@@ -798,25 +751,6 @@ __global__ void elu_bwd_kernel(const float* __restrict__ g, const float* __restr
     dz[i] = g[i] * (yy > 0.f ? 1.f : yy + 1.f);
 }
 
-// backward of one LSTM time step (pointwise part): gates (activated i,f,g,o) -> pre-activation gradients, in place
-//   dh = total gradient w.r.t. h_t, dc (in/out) = gradient w.r.t. c_t coming from step t+1 -> w.r.t. c_{t-1}
-__global__ void lstm_h_step_bwd_kernel(float* __restrict__ gates, const float* __restrict__ c, const float* __restrict__ cprev,
-                                       const float* __restrict__ dh, float* __restrict__ dc, int H, int Bn) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= H * Bn) return;
-    const size_t hb = (size_t)H * Bn;
-    const float gi = gates[i], gf = gates[hb + i], gg = gates[2 * hb + i], go = gates[3 * hb + i];
-    const float tc = tanhf(c[i]);
-    const float dht = dh[i];
-    const float dct = dc[i] + dht * go * (1.f - tc * tc);
-    const float cp = cprev ? cprev[i] : 0.f;
-    gates[i] = dct * gg * gi * (1.f - gi);
-    gates[hb + i] = dct * cp * gf * (1.f - gf);
-    gates[2 * hb + i] = dct * gi * (1.f - gg * gg);
-    gates[3 * hb + i] = dht * tc * go * (1.f - go);
-    dc[i] = dct * gf;
-}
-
 // partial[c][y] = sum over clips nb == y (mod gridDim.y) and all t of x[nb][c][t]; channel_sum_final adds the partials of a
 // channel in fixed order (bias gradient of the transposed convolutions; no atomics: bit-reproducible)
 __global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restrict__ x, float* __restrict__ partial, int NB, int C, int L) {
@@ -1073,13 +1007,6 @@ int wm_elu_bwd(const float* g, const float* y, float* dz, long long n, hipStream
     return 0;
 }
 
-int wm_lstm_h_step_bwd(float* gates, const float* c, const float* cprev, const float* dh, float* dc, int H, int Bn,
-                       hipStream_t stream) {
-    hipLaunchKernelGGL(lstm_h_step_bwd_kernel, dim3((H * Bn + 255) / 256), dim3(256), 0, stream, gates, c, cprev, dh, dc, H, Bn);
-    WM_CHECK_LAUNCH();
-    return 0;
-}
-
 // out[c] (+)= sum_{nb,t} x[nb][c][t]; partial: >= 64*C floats of scratch.  Fixed summation order (no atomics).
 int wm_channel_sum(const float* x, float* out, float* partial, int NB, int C, int L, int accumulate, hipStream_t stream) {
     if (NB <= 0 || C <= 0 || L <= 0 || !partial) return (int)hipErrorInvalidValue;
@@ -1099,16 +1026,6 @@ int wm_rowsum_any(const float* x, float* out, int rows, int L, hipStream_t strea
 
 int wm_rows_scatter_add(float* dtable, const long long* idx, const float* dvec, int Bn, int dim, int nrows, hipStream_t stream) {
     hipLaunchKernelGGL(rows_scatter_add_kernel, dim3((dim + 255) / 256), dim3(256), 0, stream, dtable, idx, dvec, Bn, dim, nrows);
-    WM_CHECK_LAUNCH();
-    return 0;
-}
-
-// one time step of an LSTM layer with hidden size H (H % 32 == 0); all tensors [rows][Bn] with Bn contiguous
-int wm_lstm_h_step_fwd(const float* xp, const float* whhT, const float* hprev, const float* cprev, float* hout, float* cout,
-                       float* gates_out, int H, int Bn, hipStream_t stream) {
-    if (H <= 0 || (H & 31) || Bn <= 0) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(lstm_h_step_fwd_kernel, dim3(H / 32, (Bn + 31) / 32), dim3(64), 0, stream, xp, whhT, hprev, cprev, hout,
-                       cout, gates_out, H, Bn);
     WM_CHECK_LAUNCH();
     return 0;
 }

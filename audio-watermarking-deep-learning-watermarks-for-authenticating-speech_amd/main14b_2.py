@@ -6,8 +6,9 @@ layout.  Forward AND backward run in csrc/gconv.hip:
     matrix-core convolution `wm_gconv` with a re-indexed weight image (re-indexing = pure data movement, done here
     with torch view ops); weight / bias gradients come from `wm_gwgrad` / `wm_channel_sum`;
   * ELU is fused into the convolution epilogue forward and is one element-wise launch backward;
-  * nn.LSTM(hd, hd, num_layers=2) over the 50 latent steps: the input projection of a whole layer is one K=1 gconv, each
-    time step is a gate GEMM on the matrix cores + cell update (`wm_lstm_h_step_fwd`), BPTT mirrors it.
+  * nn.LSTM(hd, hd, num_layers=2) over the 50 latent steps: the input projection of a whole layer is one K=1 gconv, the
+    recurrence is a chain of per-step launches issued by the C launcher (`wm_lstm_seq_fwd`: gate GEMM on the matrix cores +
+    cell update, the kernel boundary is the step barrier), BPTT mirrors it (`wm_lstm_seq_bwd`).
 """
 from __future__ import annotations
 

@@ -150,7 +150,7 @@ _CONV = {"bf16x6": _os.environ.get("WM_CONV_BF16X6", "1") == "1", "schedule": 2,
 
 
 def set_conv_bf_schedule(schedule: int):
-    """0: phase-serial kernel, 1: two-group ping-pong, 2: register-resident weights + interleaved split (csrc/conv64.hip)."""
+    """0: phase-serial kernel, 2: register-resident weights + interleaved split (csrc/conv64.hip)."""
     lib.wm_set_conv_bf_schedule(int(schedule), None)
     _CONV["schedule"] = int(schedule)
 

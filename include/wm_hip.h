@@ -59,8 +59,8 @@ int wm_conv64(const float* x, const float* x2, const float* wp, const float* pa,
  * output the gradient flows into | 2 y = conv + e1 | 3 y = conv. */
 int wm_pack_w64_bf(const float* w, void* wpb, int mode, wm_stream_t stream);
 /* schedule of wm_conv64_bf (process-wide knob; default 2): 0 phase-serial, one wave per SIMD, 128-column tiles |
- * 1 two groups of four waves half a period apart, 64-column tiles | 2 weight fragments resident in registers, input
- * image double-buffered, split / deferred epilogue / prefetch interleaved with the MFMAs (T % 128 == 0, else 0 runs) */
+ * 2 weight fragments resident in registers, input image double-buffered, split / deferred epilogue / prefetch dealt out one
+ * slice per MFMA (T % 128 == 0, else 0 runs).  Any other value selects 0. */
 int wm_set_conv_bf_schedule(int schedule, wm_stream_t stream);
 int wm_conv64_bf(const float* x, const float* x2, const void* wpb, const float* pa, const float* pb, const float* pc,
                  const float* bias, const float* e1, const float* ea, const float* eb, float* y, float* stats,
@@ -209,9 +209,6 @@ int wm_gwgrad(const float* A, const float* Bx, float* G, float* dbias, float* sl
 int wm_gather_taps(const float* x, float* y, int NB, int C, int Lin, int K, int S, int P, int Lout, int order, wm_stream_t stream);
 /* dz = g * ELU'(z) from y = ELU(z) (py/main14b_2.py:90,:96,:101) */
 int wm_elu_bwd(const float* g, const float* y, float* dz, long long n, wm_stream_t stream);
-/* pointwise backward of one LSTM step: gates (activations) -> pre-activation gradients in place; dc in/out */
-int wm_lstm_h_step_bwd(float* gates, const float* c, const float* cprev, const float* dh, float* dc, int H, int Bn,
-                       wm_stream_t stream);
 /* out[c] (+)= sum_{nb,t} x[nb][c][t] in a fixed order (partial: >= 64*C floats of scratch; accumulate 0 | 1);
  * out[row] = sum_t x[row][t] for any row length */
 int wm_channel_sum(const float* x, float* out, float* partial, int NB, int C, int L, int accumulate, wm_stream_t stream);
@@ -220,11 +217,6 @@ int wm_rowsum_any(const float* x, float* out, int rows, int L, wm_stream_t strea
 int wm_rows_scatter_add(float* dtable, const long long* idx, const float* dvec, int Bn, int dim, int nrows, wm_stream_t stream);
 /* [A][C][L] -> [L][C][A]: batch-major <-> time-major sequence layout around nn.LSTM (:137) */
 int wm_permute_acl(const float* x, float* y, int A, int C, int L, wm_stream_t stream);
-/* one time step of nn.LSTM(hd, hd, num_layers=2) (:137) for one layer: gate GEMM on the matrix cores + cell update;
- * tensors are [rows][Bn] (batch contiguous), whhT = W_hh^T [hd][4hd], hprev/cprev NULL = zero initial state          */
-int wm_lstm_h_step_fwd(const float* xp, const float* whhT, const float* hprev, const float* cprev, float* hout, float* cout,
-                       float* gates_out, int H, int Bn, wm_stream_t stream);
-
 /* one layer of nn.LSTM(hd, hd, num_layers=2) (py/main14b_2.py:137, :165) over all T steps as a chain of per-step launches
  * issued by the launcher (the kernel boundary is the step barrier): gate GEMM on the fp32 matrix cores + cell update.
  * Time-major, batch contiguous.  xp [T][4H][B] = W_ih x_t + b (activations overwrite it when save != 0); whh [4H][H];
