@@ -847,6 +847,9 @@ int launch_conv64bf(const Conv64Args& a, hipStream_t stream) {
 #ifndef WM_BF3_MANUAL
 #define WM_BF3_MANUAL 1
 #endif
+#ifndef WM_WGRAD_PIPE
+#define WM_WGRAD_PIPE 1      // k3 weight gradient: 1 = pipelined 64-step tiles (wgrad64bfp_kernel), 0 = phase-serial 128-step tiles
+#endif
 // XCD-aware workgroup -> tile-slot map.  Workgroups are dealt round-robin to the 8 XCDs (blockIdx % 8), each with its
 // own L2.  Giving XCD x the 1/8 of the tile sequence [x*G/8, (x+1)*G/8) makes time-adjacent tiles share an L2, so the
 // halo columns (a 128-B line per channel per side, +50 % fetched bytes otherwise) and the neighbours' lines hit in L2.
@@ -1949,6 +1952,342 @@ __global__ __launch_bounds__(256) void wgrad64bf_kernel(Wgrad64Args a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Pipelined build of wgrad64bf_kernel.  The kernel above runs its phases back to back on one wave per SIMD -- matrix phase,
+// barrier, prologue + split + LDS write (640 VALU instructions per lane), barrier -- and the matrix cores sit idle through
+// every VALU phase (38 % busy).  Here a tile is 64 time steps, so both 3-piece images fit twice (2 x 60 KB): while the
+// 72 MFMAs of tile i run out of one image pair, the same instruction stream prologues / splits tile i+1 into the other
+// and fetches tile i+2, ONE slice of side work (<= 8 VALU / LDS / global instructions) pinned behind each MFMA by
+// sched_barrier fences (see conv64bf3_kernel: the six MFMAs of a piece-product group chain on one accumulator and wait
+// 8 passes for each other, so a slice costs nothing).  The +-1 shifted B fragments of a column block are built while
+// its unshifted products run.  One LDS-only barrier per tile.
+// ---------------------------------------------------------------------------------------------
+template <int GPRO, int XPRO>
+__global__ __launch_bounds__(256) void wgrad64bfp_kernel(Wgrad64Args a) {
+    static_assert(XPRO == PRO_NONE || XPRO == PRO_BNRELU, "x prologue: none or BN+ReLU");
+    constexpr int KW = 3, NT = 64, NP = 3, PG = 72, PX = 88, XO = 8;   // X element index = (t - t0) + XO
+    constexpr int QR = NT / 4, NV = 64 * QR / 256;                     // 16 quads per channel row, 4 units per thread and tensor
+    constexpr bool GTWO = (GPRO == PRO_BNBWD);
+    constexpr int GIMG = NP * 64 * PG, XIMG = NP * 64 * PX;            // bf16 elements per image
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    unsigned short* Gb0 = reinterpret_cast<unsigned short*>(smem_raw);         // [2][NP][64][PG]
+    unsigned short* Xb0 = Gb0 + 2 * GIMG;                                      // [2][NP][64][PX]
+    float* Cs = reinterpret_cast<float*>(Xb0 + 2 * XIMG);                      // [6][64]
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int T = a.T;
+    const int tilesPerClip = (T + NT - 1) / NT, ntiles = a.B * tilesPerClip;
+
+    // staging coordinates (fixed per thread): unit i = channel cq + 16 i, time quad q
+    const int cq = tid >> 4, q = tid & 15;
+    const int hc = (tid & 127) >> 1, hh = tid & 1;
+    float4 sg[NV], sg2[GTWO ? NV : 1], sx[NV];
+    float hx = 0.f;
+    float bsum[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) bsum[i] = 0.f;
+
+    // operand fetch of one tile: per-tile scalar descriptors of the clip + ONE per-lane byte offset; unit i sits 16 i rows further
+    wm_srd_t dg = make_srd(a.g, 0), dg2 = dg, dx = dg;
+    unsigned voff = 0, hoff = 0;
+    bool okq = true, okh = true;                    // the unit's quad / the halo column lies inside the clip
+    auto set_tile = [&](int tile) {
+        const int b = tile / tilesPerClip, t0 = (tile - b * tilesPerClip) * NT;
+        const size_t clip = (size_t)b * 64 * T, bytes = (size_t)64 * T * sizeof(float);
+        dg = make_srd(a.g + clip, bytes);
+        if (GTWO) dg2 = make_srd(a.g2 + clip, bytes);
+        dx = make_srd(a.x + clip, bytes);
+        voff = (unsigned)(cq * T + min(t0 + 4 * q, T - 4)) * 4u;
+        const int th = hh ? t0 + NT : t0 - 1;
+        hoff = (unsigned)(hc * T + min(max(th, 0), T - 1)) * 4u;
+        okq = t0 + 4 * q < T;
+        okh = th >= 0 && th < T;
+    };
+    const unsigned rowstep = (unsigned)(16 * T) * 4u;
+    auto load_g = [&](int i) {                     // branch-free: clamped address, masked at the split
+        sg[i] = __builtin_bit_cast(float4, buf_load4(dg, voff, rowstep * i));
+        if (GTWO) sg2[i] = __builtin_bit_cast(float4, buf_load4(dg2, voff, rowstep * i));
+    };
+    auto load_x = [&](int i) { sx[i] = __builtin_bit_cast(float4, buf_load4(dx, voff, rowstep * i)); };
+    auto load_halo = [&]() { hx = buf_load(dx, hoff, 0u); };
+
+    const int tstep = gridDim.x;
+    int tile = WM_XCD_MAP ? xcd_slot() : (int)blockIdx.x;            // grid <= ntiles
+    set_tile(tile);
+    bool okq_cur = okq, okh_cur = okh;              // masks of the tile whose operands are in the registers
+#pragma unroll
+    for (int i = 0; i < NV; ++i) { load_g(i); load_x(i); }
+    load_halo();
+    if (tid < 64) {
+        Cs[tid] = GTWO ? a.ga[tid] : 0.f;
+        Cs[64 + tid] = GTWO ? a.gb[tid] : 0.f;
+        Cs[128 + tid] = GTWO ? a.gc[tid] : 0.f;
+        Cs[192 + tid] = (XPRO == PRO_BNRELU) ? a.xa[tid] : 0.f;
+        Cs[256 + tid] = (XPRO == PRO_BNRELU) ? a.xb[tid] : 0.f;
+        Cs[320 + tid] = GTWO ? a.gb[64 + tid] : 0.f;        // low word of the BatchNorm-backward offset
+    }
+    // the element right of the right halo only feeds bits that the funnel shift drops: keep it defined in both images
+    for (int i = tid; i < 2 * NP * 64; i += 256) Xb0[(i / (NP * 64)) * XIMG + (i % (NP * 64)) * PX + XO + NT + 1] = 0;
+    __syncthreads();
+    // per-thread prologue constants: the unit channels never change
+    float gca[GTWO ? NV : 1], gcb[GTWO ? NV : 1], gcc[GTWO ? NV : 1], gcl[GTWO ? NV : 1], xca[NV], xcb[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = cq + 16 * i;
+        if (GTWO) { gca[i] = Cs[c]; gcb[i] = Cs[64 + c]; gcc[i] = Cs[128 + c]; gcl[i] = Cs[320 + c]; }
+        xca[i] = Cs[192 + c]; xcb[i] = Cs[256 + c];
+    }
+    const float hxa = Cs[192 + hc], hxb = Cs[256 + hc];
+
+    // ---- the split of one staged unit (four consecutive time steps of one channel = two value pairs) in six stages
+    float va = 0.f, vb = 0.f, vc = 0.f, vd = 0.f;
+    unsigned pa0 = 0, pa1 = 0, pb0 = 0, pb1 = 0;
+    float bflag = 1.f;                  // 0 while a clamped duplicate of the last tile is being split (it must not reach the bias sums)
+    float wc = 0.f, wd = 0.f;           // second half of a two-tensor unit, parked while its registers are refilled
+    auto g_pro_a = [&](int i) {         // first value pair of unit i: prologue + mask + bias sum; the second pair is parked raw
+        const float4 v = sg[i];
+        float x0 = v.x, x1 = v.y;
+        vc = v.z; vd = v.w;
+        if (GTWO) {
+            const float4 w = sg2[i];
+            x0 = pro_apply<PRO_BNBWD>(x0, w.x, gca[i], gcb[i], gcc[i], gcl[i]); x1 = pro_apply<PRO_BNBWD>(x1, w.y, gca[i], gcb[i], gcc[i], gcl[i]);
+            wc = w.z; wd = w.w;
+        }
+        va = okq_cur ? x0 : 0.f; vb = okq_cur ? x1 : 0.f;
+        bsum[i] = fmaf(bflag, va + vb, bsum[i]);
+        asm volatile("" : "+v"(va), "+v"(vb), "+v"(vc), "+v"(vd), "+v"(wc), "+v"(wd), "+v"(bsum[i]));
+    };
+    auto g_pro_b = [&](int i) {         // second value pair
+        float x2 = vc, x3 = vd;
+        if (GTWO) { x2 = pro_apply<PRO_BNBWD>(x2, wc, gca[i], gcb[i], gcc[i], gcl[i]); x3 = pro_apply<PRO_BNBWD>(x3, wd, gca[i], gcb[i], gcc[i], gcl[i]); }
+        vc = okq_cur ? x2 : 0.f; vd = okq_cur ? x3 : 0.f;
+        bsum[i] = fmaf(bflag, vc + vd, bsum[i]);
+        asm volatile("" : "+v"(vc), "+v"(vd), "+v"(bsum[i]));
+    };
+    auto x_pro = [&](int i) {
+        float4 u = sx[i];
+        if (XPRO != PRO_NONE) {
+            u.x = pro_apply<XPRO>(u.x, 0.f, xca[i], xcb[i], 0.f); u.y = pro_apply<XPRO>(u.y, 0.f, xca[i], xcb[i], 0.f);
+            u.z = pro_apply<XPRO>(u.z, 0.f, xca[i], xcb[i], 0.f); u.w = pro_apply<XPRO>(u.w, 0.f, xca[i], xcb[i], 0.f);
+        }
+        const bool ok = okq_cur;
+        va = ok ? u.x : 0.f; vb = ok ? u.y : 0.f; vc = ok ? u.z : 0.f; vd = ok ? u.w : 0.f;
+        asm volatile("" : "+v"(va), "+v"(vb), "+v"(vc), "+v"(vd));
+    };
+    auto h_pro = [&]() {
+        float v = hx;
+        if (XPRO != PRO_NONE) v = pro_apply<XPRO>(v, 0.f, hxa, hxb, 0.f);
+        va = okh_cur ? v : 0.f; vb = 0.f;
+        asm volatile("" : "+v"(va), "+v"(vb));
+    };
+    auto s1a = [&]() {
+        const bf16x2 h_ = {(__bf16)va, (__bf16)vb};
+        pa0 = __builtin_bit_cast(unsigned, h_);
+        va -= __uint_as_float(pa0 << 16); vb -= __uint_as_float(pa0 & 0xffff0000u);
+        asm volatile("" : "+v"(va), "+v"(vb), "+v"(pa0));
+    };
+    auto s2a = [&]() {
+        const bf16x2 m_ = {(__bf16)va, (__bf16)vb};
+        pa1 = __builtin_bit_cast(unsigned, m_);
+        va -= __uint_as_float(pa1 << 16); vb -= __uint_as_float(pa1 & 0xffff0000u);
+        asm volatile("" : "+v"(va), "+v"(vb), "+v"(pa1));
+    };
+    auto s1b = [&]() {
+        const bf16x2 h_ = {(__bf16)vc, (__bf16)vd};
+        pb0 = __builtin_bit_cast(unsigned, h_);
+        vc -= __uint_as_float(pb0 << 16); vd -= __uint_as_float(pb0 & 0xffff0000u);
+        asm volatile("" : "+v"(vc), "+v"(vd), "+v"(pb0));
+    };
+    auto s2b = [&]() {
+        const bf16x2 m_ = {(__bf16)vc, (__bf16)vd};
+        pb1 = __builtin_bit_cast(unsigned, m_);
+        vc -= __uint_as_float(pb1 << 16); vd -= __uint_as_float(pb1 & 0xffff0000u);
+        asm volatile("" : "+v"(vc), "+v"(vd), "+v"(pb1));
+    };
+    auto out4 = [&](unsigned short* dst, int stride_p) {         // last stage + the three 8-byte LDS writes
+        const bf16x2 la = {(__bf16)va, (__bf16)vb}, lb = {(__bf16)vc, (__bf16)vd};
+        *reinterpret_cast<uint2*>(dst) = make_uint2(pa0, pb0);
+        *reinterpret_cast<uint2*>(dst + stride_p) = make_uint2(pa1, pb1);
+        *reinterpret_cast<uint2*>(dst + 2 * stride_p) = make_uint2(__builtin_bit_cast(unsigned, la), __builtin_bit_cast(unsigned, lb));
+    };
+    auto h_out = [&](unsigned short* X) {
+        const bf16x2 la = {(__bf16)va, (__bf16)vb};
+        const int o = hc * PX + (hh ? XO + NT : XO - 1);
+        X[o] = (unsigned short)pa0; X[64 * PX + o] = (unsigned short)pa1; X[2 * 64 * PX + o] = (unsigned short)__builtin_bit_cast(unsigned, la);
+    };
+    // Side work of one tile as a sequence of slices: the operands in the registers are split into images (G, X) and the
+    // consumed registers are refilled from the tile set_tile() last pointed at.  Units (G0, X0, G1, X1, ...), then the halo.
+    // A gradient unit takes SG slices (prologue a | hi a + refill | mid a | prologue b | hi b | mid b | lo + LDS writes),
+    // an input unit 6 (prologue | hi a + refill | mid a | hi b | mid b | lo + LDS writes), the halo 4.
+    constexpr int SG = 7, SX = 6, NSLICE = NV * (SG + SX) + 4;
+    auto side = [&](int u, unsigned short* G, unsigned short* X) __attribute__((always_inline)) {
+        if (u < NV * (SG + SX)) {
+            const int i = u / (SG + SX), r = u % (SG + SX);
+            if (r < SG) {
+                if (r == 0) g_pro_a(i);
+                if (r == 1) { s1a(); load_g(i); }
+                if (r == 2) s2a();
+                if (r == 3) g_pro_b(i);
+                if (r == 4) s1b();
+                if (r == 5) s2b();
+                if (r == 6) out4(G + (cq + 16 * i) * PG + 4 * q, 64 * PG);
+            } else {
+                const int st = r - SG;
+                if (st == 0) x_pro(i);
+                if (st == 1) { s1a(); load_x(i); }
+                if (st == 2) s2a();
+                if (st == 3) s1b();
+                if (st == 4) s2b();
+                if (st == 5) out4(X + (cq + 16 * i) * PX + XO + 4 * q, 64 * PX);
+            }
+        } else {
+            const int st = u - NV * (SG + SX);
+            if (st == 0) { h_pro(); load_halo(); }
+            if (st == 1) s1a();
+            if (st == 2) s2a();
+            if (st == 3) { if (tid < 128) h_out(X); }
+        }
+    };
+    static_assert(NSLICE <= 60, "72 MFMAs per tile, 12 of their slices build the shifted fragments");
+
+    {   // first tile: split serially while the second is fetched
+        set_tile(min(tile + tstep, ntiles - 1));
+        const bool okq_n = okq, okh_n = okh;
+#pragma unroll
+        for (int u = 0; u < NSLICE; ++u) side(u, Gb0, Xb0);
+        okq_cur = okq_n; okh_cur = okh_n;
+    }
+    __syncthreads();
+
+    f32x16 acc[KW][2][2];
+#pragma unroll
+    for (int k = 0; k < KW; ++k)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[k][mt][nt][r] = 0.f;
+
+    const int e0 = wave * 16 + 8 * half;             // this lane's 8 time steps of the tile (k index of the MFMA)
+    int buf = 0;
+#define FENCE __builtin_amdgcn_sched_barrier(0)
+    while (tile < ntiles) {
+        // registers: tile + tstep (split below into the other image pair); fetched below: tile + 2 tstep
+        bflag = (tile + tstep < ntiles) ? 1.f : 0.f;
+        set_tile(min(tile + 2 * tstep, ntiles - 1));
+        const bool okq_n = okq, okh_n = okh;
+        const unsigned short* Gc = Gb0 + buf * GIMG;
+        const unsigned short* Xc = Xb0 + buf * XIMG;
+        unsigned short* Gn = Gb0 + (buf ^ 1) * GIMG;
+        unsigned short* Xn = Xb0 + (buf ^ 1) * XIMG;
+        bf16x8 A[2][NP];
+        uint4 f[2][NP];
+        unsigned Lw[2][NP], Rw[2][NP];
+        bf16x8 Bl[NP], Br[NP];
+        auto read_b = [&](int nt) {
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                const unsigned short* xr = Xc + (p * 64 + nt * 32 + l31) * PX + XO + e0;
+                f[nt][p] = *reinterpret_cast<const uint4*>(xr);
+                Lw[nt][p] = *reinterpret_cast<const unsigned*>(xr - 2);
+                Rw[nt][p] = *reinterpret_cast<const unsigned*>(xr + 8);
+            }
+        };
+        auto shl = [&](int nt, int p) {      // fragment shifted to t - 1
+            const uint4 g = f[nt][p];
+            uint4 s_ = make_uint4(__builtin_amdgcn_alignbit(g.x, Lw[nt][p], 16), __builtin_amdgcn_alignbit(g.y, g.x, 16),
+                                  __builtin_amdgcn_alignbit(g.z, g.y, 16), __builtin_amdgcn_alignbit(g.w, g.z, 16));
+            asm volatile("" : "+v"(s_.x), "+v"(s_.y), "+v"(s_.z), "+v"(s_.w));      // built in this slice, not at its first use
+            Bl[p] = __builtin_bit_cast(bf16x8, s_);
+        };
+        auto shr = [&](int nt, int p) {      // fragment shifted to t + 1
+            const uint4 g = f[nt][p];
+            uint4 s_ = make_uint4(__builtin_amdgcn_alignbit(g.y, g.x, 16), __builtin_amdgcn_alignbit(g.z, g.y, 16),
+                                  __builtin_amdgcn_alignbit(g.w, g.z, 16), __builtin_amdgcn_alignbit(Rw[nt][p], g.w, 16));
+            asm volatile("" : "+v"(s_.x), "+v"(s_.y), "+v"(s_.z), "+v"(s_.w));
+            Br[p] = __builtin_bit_cast(bf16x8, s_);
+        };
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+                A[mt][p] = *reinterpret_cast<const bf16x8*>(Gc + (p * 64 + mt * 32 + l31) * PG + e0);
+        read_b(0);
+#pragma unroll
+        for (int m = 0; m < 72; ++m) {
+            const int nt = m / 36, tg = (m % 36) / 12, mt = (m % 12) / 6, j = m % 6;
+            const int pa = (j == 0 || j == 4) ? 1 : (j == 2 ? 2 : 0), pb = (j == 0 || j == 3) ? 1 : (j == 1 ? 2 : 0);
+            FENCE;
+            if (tg == 0)
+                acc[1][mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[mt][pa], __builtin_bit_cast(bf16x8, f[nt][pb]), acc[1][mt][nt], 0, 0, 0);
+            else if (tg == 1)
+                acc[0][mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[mt][pa], Bl[pb], acc[0][mt][nt], 0, 0, 0);
+            else
+                acc[2][mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[mt][pa], Br[pb], acc[2][mt][nt], 0, 0, 0);
+            FENCE;
+            // ---- the slice behind MFMA m
+            const int mm = m % 36;
+            if (mm < 3) shl(nt, mm);
+            else if (mm < 6) shr(nt, mm - 3);
+            else {
+                const int u = (nt == 0) ? mm - 6 : 30 + (mm - 6);          // 0..59: side-work slice index
+                if (u < NSLICE) side(u, Gn, Xn);
+            }
+            if (m == 30) read_b(1);
+            FENCE;
+        }
+        okq_cur = okq_n; okh_cur = okh_n;
+        lds_barrier();
+        tile += tstep;
+        buf ^= 1;
+    }
+#undef FENCE
+
+    float* out = a.partial + (size_t)blockIdx.x * (KW * 4096 + 64);
+    float* red = reinterpret_cast<float*>(smem_raw);          // KW*4096 floats = 48 KB <= the images (120 KB)
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int k = 0; k < KW; ++k)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int o = (k * 64 + mt * 32 + mfma_row(r, half)) * 64 + nt * 32 + l31;
+                            red[o] = (w == 0) ? acc[k][mt][nt][r] : red[o] + acc[k][mt][nt][r];
+                        }
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < KW * 4096; i += 256) out[i] = red[i];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {       // the 16 lanes of a channel row sit side by side
+        float v = bsum[i];
+        v += __shfl_xor(v, 8); v += __shfl_xor(v, 4); v += __shfl_xor(v, 2); v += __shfl_xor(v, 1);
+        if (q == 0) out[KW * 4096 + cq + 16 * i] = v;
+    }
+}
+
+template <int GPRO, int XPRO>
+int launch_wgrad64bfp(const Wgrad64Args& a, int* grid_out, hipStream_t stream) {
+    constexpr size_t lds = (size_t)(2 * 3 * 64 * 72 + 2 * 3 * 64 * 88) * 2 + 6 * 64 * sizeof(float);
+    static wm::DevOnce attr_done;
+    auto kern = wgrad64bfp_kernel<GPRO, XPRO>;
+    if (!wm::dev_done(attr_done)) {
+        WM_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        wm::dev_mark(attr_done);
+    }
+    const int ntiles = a.B * ((a.T + 63) / 64);
+    const int grid = ntiles < kNumCU ? ntiles : kNumCU;
+    *grid_out = grid;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, a);
+    WM_CHECK_LAUNCH();
+    return 0;
+}
+
 // Output-split build of the same kernel: a wave keeps one 32 x 32 block per tap instead of the whole 64 x 64 x 3 result, so the
 // workgroup needs ~200 registers per lane and can be co-resident with the LSTM recurrence kernels (side-stream overlap).
 template <int GPRO, int XPRO>
@@ -2135,6 +2474,9 @@ int launch_wgrad64bf_small(const Wgrad64Args& a, int* grid_out, hipStream_t stre
 
 template <int GPRO, int XPRO>
 int launch_wgrad64bf(const Wgrad64Args& a, int* grid_out, hipStream_t stream) {
+#if WM_WGRAD_PIPE
+    return launch_wgrad64bfp<GPRO, XPRO>(a, grid_out, stream);
+#endif
     constexpr size_t lds = (size_t)(3 * 64 * 136 + 3 * 64 * 152) * 2 + 6 * 64 * sizeof(float);
     static wm::DevOnce attr_done;
     auto kern = wgrad64bf_kernel<GPRO, XPRO>;
