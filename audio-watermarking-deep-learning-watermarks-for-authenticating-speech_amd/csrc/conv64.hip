@@ -847,6 +847,9 @@ int launch_conv64bf(const Conv64Args& a, hipStream_t stream) {
 #ifndef WM_BF3_MANUAL
 #define WM_BF3_MANUAL 1
 #endif
+#ifndef WM_BF7_PIPE
+#define WM_BF7_PIPE 1        // 7-tap convolution: 1 = register-resident weights, pipelined (T % 128 == 0), 0 = LDS weights, phase-serial
+#endif
 #ifndef WM_WGRAD_PIPE
 #define WM_WGRAD_PIPE 1      // k3 weight gradient: 1 = pipelined 64-step tiles (wgrad64bfp_kernel), 0 = phase-serial 128-step tiles
 #endif
@@ -1734,6 +1737,224 @@ int launch_conv64bf7(const Conv64Args& a, hipStream_t stream) {
 }
 
 // bf16 three-piece image [piece][tap][out][in] of a 7-tap ConvTranspose1d weight w[in][out][7]: mode 2 forward, 3 dgrad
+// ---------------------------------------------------------------------------------------------
+// Pipelined build of the 7-tap convolution (conv64bf3_kernel's scheme with KW = 7).  conv64bf7_kernel above keeps the
+// weight image in LDS (97 KB per output half), so two workgroups split every input tile twice and the matrix cores idle
+// through each split phase.  Here wave (mt, nh) keeps the weight fragments of its 32 output rows in REGISTERS for the whole
+// kernel (28 k-steps x 3 pieces x 4 = 336 of the 512 a lone resident wave may use), one workgroup computes all 64 rows of
+// a 128-column tile (336 MFMAs per wave), and LDS only carries the input image, double-buffered (2 x 58 KB): the split of
+// tile i+1 and the fetch of tile i+2 ride, one hand-pinned slice per MFMA, in the matrix phase of tile i.  T % 128 == 0.
+// ---------------------------------------------------------------------------------------------
+template <int PRO, int EPI>
+__global__ __launch_bounds__(256) void conv64bf7p_kernel(Conv64Args a) {
+    static_assert(PRO == PRO_NONE || PRO == PRO_ADDVEC, "prologue: none or + vec[b][c]");
+    constexpr int KW = 7, PAD = 3, NT = 128, ROWS = NT + 2 * PAD, PITCH = 72, NP = 3, NC = 4, NS = KW * 4;
+    constexpr int XBUF = NP * ROWS * PITCH;               // bf16 elements per input image
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    unsigned short* Xb0 = reinterpret_cast<unsigned short*>(smem_raw);             // 2 x [NP][ROWS][PITCH]
+    float* Cs = reinterpret_cast<float*>(Xb0 + 2 * XBUF);                           // [64] bias
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int mt = wave & 1, nh = wave >> 1;
+    const int T = a.T;                             // T % 128 == 0 (checked by the launcher): no partial tiles
+    const int tilesPerClip = T / NT, ntiles = a.B * tilesPerClip;
+
+    // ---- resident weight fragments: packed image [NP][KW][64 out][64 in] bf16; k-step s = tap * 4 + 16-channel block
+    bf16x8 Wr[NS][NP];
+    {
+        const uint4* wg = reinterpret_cast<const uint4*>(a.wp);
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                const int e = ((p * KW + (s >> 2)) * 64 + 32 * mt + l31) * 64 + 16 * (s & 3) + 8 * half;
+                Wr[s][p] = __builtin_bit_cast(bf16x8, wg[e >> 3]);
+            }
+    }
+    // ---- staging map (fixed per thread): channel pair cp, time quads q0 + 8 i; halo element k: channel hcn[k], image row hr[k]
+    const int cp = wave * 8 + (lane & 7), c0 = 2 * cp, q0 = lane >> 3;
+    int hcn[2], hr[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int idx = min(tid + k * 256, 64 * 2 * PAD - 1), h = idx % (2 * PAD);
+        hcn[k] = idx / (2 * PAD);
+        hr[k] = (h < PAD) ? h : NT + h;                                             // time = t0 - PAD + row
+    }
+    float4 sa[NC], sb[NC];
+    float hl[2];
+    float pv0 = 0.f, pv1 = 0.f, hv[2] = {0.f, 0.f};      // ADDVEC: the embedding values of the clip whose tile sits in the registers
+    float nv0 = 0.f, nv1 = 0.f, nhv[2] = {0.f, 0.f};     // ... and of the tile being fetched
+    auto load_combo = [&](int tile, int i) {
+        const int b = tile / tilesPerClip, t0 = (tile - b * tilesPerClip) * NT;
+        const size_t o = ((size_t)b * 64 + c0) * T + t0 + 4 * (q0 + 8 * i);
+        sa[i] = *reinterpret_cast<const float4*>(a.x + o);
+        sb[i] = *reinterpret_cast<const float4*>(a.x + o + T);
+    };
+    auto load_halo = [&](int tile) {              // branch-free: clamped addresses, masked when written to LDS
+        const int b = tile / tilesPerClip, t0 = (tile - b * tilesPerClip) * NT;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            hl[k] = a.x[((size_t)b * 64 + hcn[k]) * T + min(max(t0 - PAD + hr[k], 0), T - 1)];
+            if (PRO == PRO_ADDVEC) nhv[k] = a.pa[b * 64 + hcn[k]];
+        }
+        if (PRO == PRO_ADDVEC) { nv0 = a.pa[b * 64 + c0]; nv1 = a.pa[b * 64 + c0 + 1]; }
+    };
+
+    const int tstep = gridDim.x;
+    int tile = WM_XCD_MAP ? xcd_slot() : (int)blockIdx.x;        // grid <= ntiles
+#pragma unroll
+    for (int i = 0; i < NC; ++i) load_combo(tile, i);
+    load_halo(tile);
+    if (tid < 64) Cs[tid] = (EPI == EPI_BIAS && a.bias) ? a.bias[tid] : 0.f;
+
+    // ---- the split of one (combo i, element e) unit = two channels x one time step, in four stages (one slice each)
+    float sva = 0.f, svb = 0.f;
+    unsigned sp0 = 0, sp1 = 0;
+    auto split_pick = [&](int i, int e) {
+        const float4 fa = sa[i], fb = sb[i];
+        float va = (e == 0) ? fa.x : (e == 1) ? fa.y : (e == 2) ? fa.z : fa.w;
+        float vb = (e == 0) ? fb.x : (e == 1) ? fb.y : (e == 2) ? fb.z : fb.w;
+        if (PRO == PRO_ADDVEC) { va += pv0; vb += pv1; }
+        sva = va; svb = vb;
+        asm volatile("" : "+v"(sva), "+v"(svb));
+    };
+    auto split_st1 = [&]() {
+        const bf16x2 h_ = {(__bf16)sva, (__bf16)svb};
+        sp0 = __builtin_bit_cast(unsigned, h_);
+        sva -= __uint_as_float(sp0 << 16); svb -= __uint_as_float(sp0 & 0xffff0000u);
+        asm volatile("" : "+v"(sva), "+v"(svb), "+v"(sp0));
+    };
+    auto split_st2 = [&]() {
+        const bf16x2 m_ = {(__bf16)sva, (__bf16)svb};
+        sp1 = __builtin_bit_cast(unsigned, m_);
+        sva -= __uint_as_float(sp1 << 16); svb -= __uint_as_float(sp1 & 0xffff0000u);
+        asm volatile("" : "+v"(sva), "+v"(svb), "+v"(sp1));
+    };
+    auto split_out = [&](unsigned short* X, int i, int e) {
+        const bf16x2 l_ = {(__bf16)sva, (__bf16)svb};
+        unsigned* X32 = reinterpret_cast<unsigned*>(X);
+        const int o = (PAD + 4 * (q0 + 8 * i) + e) * (PITCH / 2) + cp;
+        X32[o] = sp0; X32[(ROWS * PITCH >> 1) + o] = sp1; X32[2 * (ROWS * PITCH >> 1) + o] = __builtin_bit_cast(unsigned, l_);
+    };
+    auto halo_pick = [&](int t0, int k) {
+        const int t = t0 - PAD + hr[k];
+        float v = hl[k];
+        if (PRO == PRO_ADDVEC) v += hv[k];
+        sva = (t < 0 || t >= T) ? 0.f : v; svb = 0.f;
+        asm volatile("" : "+v"(sva), "+v"(svb));
+    };
+    auto halo_out = [&](unsigned short* X, int k) {
+        const bf16x2 l_ = {(__bf16)sva, (__bf16)svb};
+        if (tid + k * 256 < 64 * 2 * PAD) {
+            const int o = hr[k] * PITCH + hcn[k];
+            X[o] = (unsigned short)sp0; X[ROWS * PITCH + o] = (unsigned short)sp1; X[2 * ROWS * PITCH + o] = (unsigned short)__builtin_bit_cast(unsigned, l_);
+        }
+    };
+    {   // first tile: split serially, then fetch the second
+        const int t0 = (tile % tilesPerClip) * NT;
+        pv0 = nv0; pv1 = nv1; hv[0] = nhv[0]; hv[1] = nhv[1];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { split_pick(u >> 2, u & 3); split_st1(); split_st2(); split_out(Xb0, u >> 2, u & 3); }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) { halo_pick(t0, k); split_st1(); split_st2(); halo_out(Xb0, k); }
+        const int nx = min(tile + tstep, ntiles - 1);
+#pragma unroll
+        for (int i = 0; i < NC; ++i) load_combo(nx, i);
+        load_halo(nx);
+    }
+    __syncthreads();
+
+    int buf = 0;
+#define FENCE __builtin_amdgcn_sched_barrier(0)
+    while (tile < ntiles) {
+        // registers: the operands of tile + tstep (clamped: a tile past the end lands in the image nobody reads again)
+        const int next = min(tile + tstep, ntiles - 1), next2 = min(tile + 2 * tstep, ntiles - 1);
+        const int b = tile / tilesPerClip, t0 = (tile - b * tilesPerClip) * NT;
+        const int nt0 = (next % tilesPerClip) * NT;
+        const unsigned short* xcur = Xb0 + buf * XBUF;
+        unsigned short* xnxt = Xb0 + (buf ^ 1) * XBUF;
+        f32x16 acc[2];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+        const unsigned short* xrow = xcur + (64 * nh + l31) * PITCH + 8 * half;
+        bf16x8 Bq[2][NP];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) Bq[0][p] = *reinterpret_cast<const bf16x8*>(xrow + p * ROWS * PITCH);
+        // the embedding values of the tile in the registers become current; load_halo() below refills the "next" set
+        pv0 = nv0; pv1 = nv1; hv[0] = nhv[0]; hv[1] = nhv[1];
+#define BF7_SLICE(k)                                                                                                        \
+    {                                                                                                                           \
+        if (h < 16) {                                                                                                           \
+            if ((k) == 0) split_pick(h >> 2, h & 3);                                                                            \
+            if ((k) == 1) split_st1();                                                                                          \
+            if ((k) == 2) split_st2();                                                                                          \
+            if ((k) == 3) { split_out(xnxt, h >> 2, h & 3); if ((h & 3) == 3) load_combo(next2, h >> 2); }                      \
+        } else if (h < 18) {                                                                                                    \
+            if ((k) == 0) halo_pick(nt0, h - 16);                                                                               \
+            if ((k) == 1) split_st1();                                                                                          \
+            if ((k) == 2) split_st2();                                                                                          \
+            if ((k) == 3) halo_out(xnxt, h - 16);                                                                               \
+        } else if (h == 18) {                                                                                                   \
+            if ((k) == 0) load_halo(next2);                                                                                     \
+        }                                                                                                                       \
+    }
+#pragma unroll
+        for (int h = 0; h < 2 * NS; ++h) {
+            const int s = h >> 1, nt = h & 1;
+            if (h + 1 < 2 * NS) {
+                const int s1_ = (h + 1) >> 1, n1 = (h + 1) & 1;
+#pragma unroll
+                for (int p = 0; p < NP; ++p)
+                    Bq[(h + 1) & 1][p] = *reinterpret_cast<const bf16x8*>(xrow + (p * ROWS + 32 * n1 + (s1_ >> 2)) * PITCH + 16 * (s1_ & 3));
+            }
+            const bf16x8* Bf = Bq[h & 1];
+            FENCE;
+            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wr[s][1], Bf[1], acc[nt], 0, 0, 0); FENCE; BF7_SLICE(0) FENCE;
+            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wr[s][0], Bf[2], acc[nt], 0, 0, 0); FENCE; BF7_SLICE(1) FENCE;
+            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wr[s][2], Bf[0], acc[nt], 0, 0, 0); FENCE; BF7_SLICE(2) FENCE;
+            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wr[s][0], Bf[1], acc[nt], 0, 0, 0); FENCE; BF7_SLICE(3) FENCE;
+            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wr[s][1], Bf[0], acc[nt], 0, 0, 0); FENCE;
+            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wr[s][0], Bf[0], acc[nt], 0, 0, 0); FENCE;
+        }
+#undef BF7_SLICE
+        // epilogue (serial: 32 values against 336 MFMAs)
+        {
+            float* yb = a.y + ((size_t)b * 64 + 32 * mt + 4 * half) * T + t0 + 64 * nh + l31;
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2);
+                    float v = acc[nt][r];
+                    if (EPI == EPI_BIAS) v += Cs[32 * mt + 4 * half + row];
+                    yb[(size_t)row * T + 32 * nt] = v;
+                }
+        }
+        lds_barrier();
+        tile += tstep;
+        buf ^= 1;
+    }
+#undef FENCE
+}
+
+template <int PRO, int EPI>
+int launch_conv64bf7p(const Conv64Args& a, hipStream_t stream) {
+    constexpr size_t lds = (size_t)(2 * 3 * 134 * 72) * 2 + 64 * sizeof(float);
+    static wm::DevOnce attr_done;
+    auto kern = conv64bf7p_kernel<PRO, EPI>;
+    if (!wm::dev_done(attr_done)) {
+        WM_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        wm::dev_mark(attr_done);
+    }
+    const int ntiles = a.B * (a.T / 128);
+    const int grid = ntiles < kNumCU ? ntiles : kNumCU;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, a);
+    WM_CHECK_LAUNCH();
+    return 0;
+}
+
 __global__ void pack_w64_bf7_kernel(const float* __restrict__ w, unsigned short* __restrict__ wpb, int mode) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= 7 * 4096) return;
@@ -2786,6 +3007,13 @@ int wm_conv64_bf7(const float* x, const void* wpb, const float* vec, const float
                   hipStream_t stream) {
     if (B <= 0 || T <= 0 || (T & 3)) return (int)hipErrorInvalidValue;
     Conv64Args a{x, nullptr, reinterpret_cast<const float*>(wpb), vec, nullptr, nullptr, bias, nullptr, nullptr, nullptr, y, nullptr, B, T};
+#if WM_BF7_PIPE
+    if ((T & 127) == 0) {                 // register-resident weights + double-buffered input image (conv64bf7p_kernel)
+        if (pro == PRO_NONE && epi == EPI_BIAS) return launch_conv64bf7p<PRO_NONE, EPI_BIAS>(a, stream);
+        if (pro == PRO_ADDVEC && epi == EPI_BIAS) return launch_conv64bf7p<PRO_ADDVEC, EPI_BIAS>(a, stream);
+        if (pro == PRO_NONE && epi == EPI_NONE) return launch_conv64bf7p<PRO_NONE, EPI_NONE>(a, stream);
+    }
+#endif
     if (pro == PRO_NONE && epi == EPI_BIAS) return launch_conv64bf7<PRO_NONE, EPI_BIAS>(a, stream);
     if (pro == PRO_ADDVEC && epi == EPI_BIAS) return launch_conv64bf7<PRO_ADDVEC, EPI_BIAS>(a, stream);
     if (pro == PRO_NONE && epi == EPI_NONE) return launch_conv64bf7<PRO_NONE, EPI_NONE>(a, stream);
