@@ -243,15 +243,21 @@ class ResBlockFn(GradAwareFunction):
             _conv3(y1, None, w2, 0, sc1, sh1, None, b2, None, None, None, y2, None, B, T, 1, 0)
             # saved (mean, invstd) for an eval-mode backward = running statistics
             mu1.copy_(rm1); is1.copy_(torch.rsqrt(rv1 + BN_EPS)); mu2.copy_(rm2); is2.copy_(torch.rsqrt(rv2 + BN_EPS))
-        lib.wm_bn_add_relu(_p(x), _p(y2), _p(sc2), _p(sh2), _p(out), B, T, st)
+        if wants_grad(ctx):
+            # the backward needs only the SIGN of `out`: one bit per element, written beside it (a frame pass less in backward)
+            mask = torch.empty(B * 64 * 16 * ((T + 1023) // 1024), dtype=torch.int64, device=dev)
+            lib.wm_bn_add_relu_mask(_p(x), _p(y2), _p(sc2), _p(sh2), _p(out), _p(mask), B, T, st)
+        else:
+            mask = None
+            lib.wm_bn_add_relu(_p(x), _p(y2), _p(sc2), _p(sh2), _p(out), B, T, st)
         ctx.training = bool(training)
         ctx.gdst = _gdst(w1, b1, w2, b2)
-        ctx.save_for_backward(x, y1, y2, out, cst, w1, w2, g1, g2)
+        ctx.save_for_backward(x, y1, y2, mask, cst, w1, w2, g1, g2)
         return out
 
     @staticmethod
     def backward(ctx, g_out):
-        x, y1, y2, out, cst, w1, w2, g1, g2 = ctx.saved_tensors
+        x, y1, y2, mask, cst, w1, w2, g1, g2 = ctx.saved_tensors
         sc1, sh1, mu1, is1, sc2, sh2, mu2, is2 = cst.unbind(0)
         g_out = g_out.contiguous()
         B, _, T = x.shape
@@ -260,7 +266,7 @@ class ResBlockFn(GradAwareFunction):
         n = float(B * T)
         dz2 = torch.empty_like(x)
         part = _f32(max(B, 1) * 128, device=dev)
-        lib.wm_relu_bwd_reduce(_p(g_out), _p(out), _p(y2), _p(dz2), _p(part), B, T, st)
+        lib.wm_relu_bwd_reduce_mask(_p(g_out), _p(mask), _p(y2), _p(dz2), _p(part), B, T, st)
         k2 = _f32(4, 64, device=dev)          # A, B (hi), B (lo), C  -- B is handed over as hi + lo words
         dg2, dbe2 = _f32(64, device=dev), _f32(64, device=dev)
         lib.wm_bn_bwd_finalize(_p(part), B, n, _p(g2), _p(mu2), _p(is2), _p(k2[0]), _p(k2[1]), _p(k2[3]), _p(dg2), _p(dbe2), 0, ev, st)

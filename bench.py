@@ -187,6 +187,11 @@ def build_workload(model, mode, batch, rank, world, dev, torch_adam=False, force
         # args: x wp bias vec res y NB Cin Lin K S P Mtot Nout st shp Cout Lout act stream
         timer = LaunchTimer(awm_amd.lib, "wm_gconv", lambda a: a[12] > 64 and a[13] > 64 and a[12] % 4 == 0,
                             lambda a: (2.0 * a[6] * a[7] * a[9] * a[12] * a[13], 4.0 * a[6] * (a[7] * a[8] + a[16] * a[17])))
+    elif bf_mode and mode == "fwd" and _ops._CONV["one_launch_eval"]:
+        # inference: the ResBlock is ONE launch (two 64->64 k3 convolutions back to back; x in, out out)
+        # args: x w1pb w2pb b1 sc1 sh1 b2 sc2 sh2 y B T stream
+        timer = LaunchTimer(awm_amd.lib, "wm_resblock_eval_bf", lambda a: True,
+                            lambda a: (2.0 * 2.0 * 64 * 64 * 3 * a[11] * a[10], 2.0 * 64 * a[11] * 4 * a[10]))
     elif bf_mode:
         # dominant kernel: the 64->64 k3 forward convolution of the ResBlocks (epi = bias): wm_conv64_bf (bf16x6 split build)
         timer = LaunchTimer(awm_amd.lib, "wm_conv64_bf", lambda a: a[15] == 0,
@@ -242,6 +247,9 @@ def run_workload(model, mode, batch, steps, warmup, rank, world, dev, dist, torc
             kernel = ("conv64bf3_kernel forward (wm_conv64_bf: Conv1d(64,64,3)+bias as bf16x6 split products on the bf16 matrix cores, "
                       "fp32 accumulate, fp32-grade error; BN+ReLU fused on load, BN sums in epilogue)") if bf_mode else \
                 "conv64_kernel<KW=3> forward (wm_conv64: native fp32 MFMA; BN+ReLU fused on load, BN sums in epilogue)"
+            if timer.name == "wm_resblock_eval_bf":
+                kernel = ("resblock_eval_kernel (wm_resblock_eval_bf: the inference ResBlock in one launch -- conv1 + BN1 + ReLU, the "
+                          "intermediate kept in LDS as bf16x3 pieces, conv2 + BN2 + residual + ReLU; bf16x6 split products)")
             pref = ("conv64bf3_kernel<0, 0", "conv64bf3_kernel<1, 0") if bf_mode else ("conv64_kernel<3, 256",)
             traffic = pmc_traffic(PMC_MAIN16, pref) if batch == 256 else None
         roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",

@@ -110,6 +110,13 @@ int wm_bn_add_relu(const float* x, const float* y2, const float* scale, const fl
                    wm_stream_t stream);
 int wm_relu_bwd_reduce(const float* g, const float* out, const float* y2, float* dz, float* partial, int B, int T,
                        wm_stream_t stream);
+/* The same pair with the sign of `out` carried as one bit per element (mask: 16 * ceil(T / 1024) 64-bit words per (clip,
+ * channel) row, B * 64 rows; an opaque layout shared by the two kernels): the backward then reads g, y2 and 3 % of a frame
+ * instead of g, out, y2.  What ResBlock training uses. */
+int wm_bn_add_relu_mask(const float* x, const float* y2, const float* scale, const float* shift, float* out, void* mask, int B, int T,
+                        wm_stream_t stream);
+int wm_relu_bwd_reduce_mask(const float* g, const void* mask, const float* y2, float* dz, float* partial, int B, int T,
+                            wm_stream_t stream);
 /* A, Cc: [64]; Bc: [2][64] (hi, lo words of the offset, see wm_conv64 pro 3) */
 int wm_bn_bwd_finalize(const float* partials, int nparts, double count, const float* gamma, const float* save_mean,
                        const float* save_invstd, float* A, float* Bc, float* Cc, float* dgamma, float* dbeta,
