@@ -2891,6 +2891,471 @@ int launch_wgrad64bf7(const Wgrad64Args& a, int* grid_out, hipStream_t stream) {
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Data gradient AND weight gradient of a k3 convolution in ONE launch (ResBlock backward, py/main16.py:112-125 under
+// autograd).  Both read the same gradient frames (dz, and y for the BatchNorm-backward rebuild g = A dz + B + C y): as two
+// launches the pair moves 7 frames, fused 4 (conv2: dz2 y2 y1 in, dz1 out) or 5 (conv1: dz1 y1 x dz2 in, dx out).
+// A workgroup walks 64-step tiles.  The staging thread holds two channels x four steps of the gradient, rebuilds g once and
+// splits it twice: time pairs into the [channel][time] image of the weight gradient (phase A), channel pairs into the
+// [time][channel] image of the data gradient (phase B).  Per tile and wave:
+//   phase A: 72 MFMAs of the data gradient (weight fragments of its 32 output rows resident in registers, as conv64bf3)
+//            out of image D(i); side work: tile i+1 -> images G'(i+1), X'(i+1) (double-buffered), the epilogue operand of tile i
+//   barrier
+//   phase B: 72 MFMAs of the weight gradient (one 32 x 32 block of each tap per wave, as wgrad64bf_small) out of G'(i), X'(i);
+//            side work: tile i+1 -> image D (single-buffered), epilogue of the data gradient of tile i, refill for tile i+2
+//   barrier
+// One slice of side work pinned behind every MFMA.  LDS: 28 + 2 x 27 + 2 x 33 KB.  T % 64 == 0.
+// ---------------------------------------------------------------------------------------------
+struct DWArgs {
+    const float* g;  const float* g2;                   // gradient dz and the BN input y [B,64,T]
+    const float* ga; const float* gb; const float* gc;  // g = ga[c] dz + gb[c] (+ gb[64+c]) + gc[c] y
+    const void* wp;                                     // data-gradient weight image (wm_pack_w64_bf mode 1)
+    const float* x;  const float* xa; const float* xb;  // weight-gradient input operand (+ BN+ReLU constants when XPRO = BNRELU)
+    const float* e1; const float* ea; const float* eb;  // data-gradient epilogue tensor (RELUMASK: pre-BN activation + its scale/shift; ADD: addend)
+    float* y;                                           // data gradient out [B,64,T]
+    float* stats;                                       // [grid][2][64] (RELUMASK) or null
+    float* partial;                                     // weight-gradient slabs [grid][3*4096 + 64]
+    int B, T;
+};
+
+template <int EPI, int XPRO>
+__global__ __launch_bounds__(256) void dwgrad64bf_kernel(DWArgs a) {
+    static_assert((EPI == EPI_RELUMASK && XPRO == PRO_BNRELU) || (EPI == EPI_ADD && XPRO == PRO_NONE), "conv2 pair or conv1 pair");
+    constexpr int KW = 3, NT = 64, NP = 3, ROWS = NT + 2, PITCH = 72, PG = 72, PX = 88, XO = 8;
+    constexpr bool STATS = (EPI == EPI_RELUMASK);
+    constexpr int DIMG = NP * ROWS * PITCH, GIMG = NP * 64 * PG, XIMG = NP * 64 * PX;
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    unsigned short* Db = reinterpret_cast<unsigned short*>(smem_raw);          // [NP][ROWS][PITCH]   row r = time t0 - 1 + r
+    unsigned short* Gb0 = Db + DIMG;                                           // [2][NP][64][PG]
+    unsigned short* Xb0 = Gb0 + 2 * GIMG;                                      // [2][NP][64][PX]     element XO + (t - t0)
+    float* Cs = reinterpret_cast<float*>(Xb0 + 2 * XIMG);                      // [8][64]
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int mt = wave & 1, nh = wave >> 1;           // data gradient: 32 output rows x 32 columns; weight gradient: block (mt, nt = nh)
+    const int T = a.T;
+    const int tilesPerClip = T / NT, ntiles = a.B * tilesPerClip;
+
+    // ---- resident data-gradient weight fragments
+    bf16x8 Wr[12][NP];
+    {
+        const uint4* wg = reinterpret_cast<const uint4*>(a.wp);
+#pragma unroll
+        for (int s = 0; s < 12; ++s)
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                const int e = ((p * KW + (s >> 2)) * 64 + 32 * mt + l31) * 64 + 16 * (s & 3) + 8 * half;
+                Wr[s][p] = __builtin_bit_cast(bf16x8, wg[e >> 3]);
+            }
+    }
+    // ---- staging map: channel pair cp (channels c0, c0 + 1), unit u = time quad q0 + 8 u; halo: channel hc, side hh
+    const int cp = wave * 8 + (lane & 7), c0 = 2 * cp, q0 = lane >> 3;
+    const int hc = (tid & 127) >> 1, hh = tid & 1;
+    float4 ra_[2], rb_[2], ya_[2], yb_[2], xa_[2], xb_[2];     // raw, per unit: dz / y of channel c0 (a) and c0 + 1 (b); x of both
+    float4 ga_[2], gb_[2];                                     // the rebuilt gradient of the tile being split (phase A -> phase B)
+    float hg = 0.f, hy = 0.f, hxv = 0.f;
+    wm_srd_t dsg = make_srd(a.g, 0), dsy = dsg, dsx = dsg;
+    unsigned voff = 0, hoff = 0;
+    bool okh = true;
+    auto set_tile = [&](int tile) {
+        const int b = tile / tilesPerClip, t0 = (tile - b * tilesPerClip) * NT;
+        const size_t clip = (size_t)b * 64 * T, bytes = (size_t)64 * T * sizeof(float);
+        dsg = make_srd(a.g + clip, bytes);
+        dsy = make_srd(a.g2 + clip, bytes);
+        dsx = make_srd(a.x + clip, bytes);
+        voff = (unsigned)(c0 * T + t0 + 4 * q0) * 4u;
+        const int th = hh ? t0 + NT : t0 - 1;
+        hoff = (unsigned)(hc * T + min(max(th, 0), T - 1)) * 4u;
+        okh = th >= 0 && th < T;
+    };
+    const unsigned rowT = (unsigned)T * 4u;
+    auto load_g = [&](int u) {
+        ra_[u] = __builtin_bit_cast(float4, buf_load4(dsg, voff + 128u * u, 0u));
+        rb_[u] = __builtin_bit_cast(float4, buf_load4(dsg, voff + 128u * u, rowT));
+        ya_[u] = __builtin_bit_cast(float4, buf_load4(dsy, voff + 128u * u, 0u));
+        yb_[u] = __builtin_bit_cast(float4, buf_load4(dsy, voff + 128u * u, rowT));
+    };
+    auto load_x = [&](int u) {
+        xa_[u] = __builtin_bit_cast(float4, buf_load4(dsx, voff + 128u * u, 0u));
+        xb_[u] = __builtin_bit_cast(float4, buf_load4(dsx, voff + 128u * u, rowT));
+    };
+    auto load_ghalo = [&]() { hg = buf_load(dsg, hoff, 0u); hy = buf_load(dsy, hoff, 0u); };
+    auto load_xhalo = [&]() { hxv = buf_load(dsx, hoff, 0u); };
+
+    const int tstep = gridDim.x;
+    int tile = WM_XCD_MAP ? xcd_slot() : (int)blockIdx.x;          // grid <= ntiles
+    set_tile(tile);
+    bool okh_cur = okh;
+    load_g(0); load_g(1); load_x(0); load_x(1); load_ghalo(); load_xhalo();
+    if (tid < 64) {
+        Cs[tid] = a.ga[tid];
+        Cs[64 + tid] = a.gb[tid];
+        Cs[128 + tid] = a.gc[tid];
+        Cs[192 + tid] = a.gb[64 + tid];                  // low word of the BatchNorm-backward offset
+        Cs[256 + tid] = (XPRO == PRO_BNRELU) ? a.xa[tid] : 0.f;
+        Cs[320 + tid] = (XPRO == PRO_BNRELU) ? a.xb[tid] : 0.f;
+        Cs[384 + tid] = (EPI == EPI_RELUMASK) ? a.ea[tid] : 0.f;
+        Cs[448 + tid] = (EPI == EPI_RELUMASK) ? a.eb[tid] : 0.f;
+    }
+    // the element right of the right halo only feeds bits that the funnel shift drops: keep it defined in both images
+    for (int i = tid; i < 2 * NP * 64; i += 256) Xb0[(i / (NP * 64)) * XIMG + (i % (NP * 64)) * PX + XO + NT + 1] = 0;
+    __syncthreads();
+    // per-thread constants (the staging channels never change)
+    float kga[2], kgb[2], kgc[2], kgl[2], kxa[2], kxb[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        kga[j] = Cs[c0 + j]; kgb[j] = Cs[64 + c0 + j]; kgc[j] = Cs[128 + c0 + j]; kgl[j] = Cs[192 + c0 + j];
+        kxa[j] = Cs[256 + c0 + j]; kxb[j] = Cs[320 + c0 + j];
+    }
+    const float hga = Cs[hc], hgb = Cs[64 + hc], hgc = Cs[128 + hc], hgl = Cs[192 + hc], hxa = Cs[256 + hc], hxb = Cs[320 + hc];
+
+    // ---- split stages on a value pair (va, vb) -> pieces (p0, p1, [lo]) and a second pair (vc, vd) -> (q0_, q1_, [lo])
+    float va = 0.f, vb = 0.f, vc = 0.f, vd = 0.f;
+    unsigned p0 = 0, p1 = 0, r0 = 0, r1 = 0;
+    float bsum[2] = {0.f, 0.f};
+    float bflag = 1.f;
+    auto s1a = [&]() {
+        const bf16x2 h_ = {(__bf16)va, (__bf16)vb};
+        p0 = __builtin_bit_cast(unsigned, h_);
+        va -= __uint_as_float(p0 << 16); vb -= __uint_as_float(p0 & 0xffff0000u);
+        asm volatile("" : "+v"(va), "+v"(vb), "+v"(p0));
+    };
+    auto s2a = [&]() {
+        const bf16x2 m_ = {(__bf16)va, (__bf16)vb};
+        p1 = __builtin_bit_cast(unsigned, m_);
+        va -= __uint_as_float(p1 << 16); vb -= __uint_as_float(p1 & 0xffff0000u);
+        asm volatile("" : "+v"(va), "+v"(vb), "+v"(p1));
+    };
+    auto s1b = [&]() {
+        const bf16x2 h_ = {(__bf16)vc, (__bf16)vd};
+        r0 = __builtin_bit_cast(unsigned, h_);
+        vc -= __uint_as_float(r0 << 16); vd -= __uint_as_float(r0 & 0xffff0000u);
+        asm volatile("" : "+v"(vc), "+v"(vd), "+v"(r0));
+    };
+    auto s2b = [&]() {
+        const bf16x2 m_ = {(__bf16)vc, (__bf16)vd};
+        r1 = __builtin_bit_cast(unsigned, m_);
+        vc -= __uint_as_float(r1 << 16); vd -= __uint_as_float(r1 & 0xffff0000u);
+        asm volatile("" : "+v"(vc), "+v"(vd), "+v"(r1));
+    };
+    auto out4 = [&](unsigned short* dst, int stride_p) {         // two time pairs of one channel row: 8-byte writes
+        const bf16x2 la = {(__bf16)va, (__bf16)vb}, lb = {(__bf16)vc, (__bf16)vd};
+        *reinterpret_cast<uint2*>(dst) = make_uint2(p0, r0);
+        *reinterpret_cast<uint2*>(dst + stride_p) = make_uint2(p1, r1);
+        *reinterpret_cast<uint2*>(dst + 2 * stride_p) = make_uint2(__builtin_bit_cast(unsigned, la), __builtin_bit_cast(unsigned, lb));
+    };
+    // gradient rebuild of channel j of unit u from the raw staging registers (free for the refill afterwards): two slices
+    auto g_build = [&](int u, int j, int hf) {
+        const float4 dz = j ? rb_[u] : ra_[u], yy = j ? yb_[u] : ya_[u];
+        float4& gz = j ? gb_[u] : ga_[u];
+        if (hf == 0) {
+            gz.x = pro_apply<PRO_BNBWD>(dz.x, yy.x, kga[j], kgb[j], kgc[j], kgl[j]);
+            gz.y = pro_apply<PRO_BNBWD>(dz.y, yy.y, kga[j], kgb[j], kgc[j], kgl[j]);
+            bsum[j] = fmaf(bflag, gz.x + gz.y, bsum[j]);
+            asm volatile("" : "+v"(gz.x), "+v"(gz.y), "+v"(bsum[j]));
+        } else {
+            gz.z = pro_apply<PRO_BNBWD>(dz.z, yy.z, kga[j], kgb[j], kgc[j], kgl[j]);
+            gz.w = pro_apply<PRO_BNBWD>(dz.w, yy.w, kga[j], kgb[j], kgc[j], kgl[j]);
+            bsum[j] = fmaf(bflag, gz.z + gz.w, bsum[j]);
+            asm volatile("" : "+v"(gz.z), "+v"(gz.w), "+v"(bsum[j]));
+        }
+    };
+    auto g_pick_t = [&](int u, int j) {                         // time pairs of channel j of unit u
+        const float4 gz = j ? gb_[u] : ga_[u];
+        va = gz.x; vb = gz.y; vc = gz.z; vd = gz.w;
+        asm volatile("" : "+v"(va), "+v"(vb), "+v"(vc), "+v"(vd));
+    };
+    auto x_pick_t = [&](int u, int j) {
+        float4 xx = j ? xb_[u] : xa_[u];
+        if (XPRO == PRO_BNRELU) {
+            xx.x = pro_apply<PRO_BNRELU>(xx.x, 0.f, kxa[j], kxb[j], 0.f); xx.y = pro_apply<PRO_BNRELU>(xx.y, 0.f, kxa[j], kxb[j], 0.f);
+            xx.z = pro_apply<PRO_BNRELU>(xx.z, 0.f, kxa[j], kxb[j], 0.f); xx.w = pro_apply<PRO_BNRELU>(xx.w, 0.f, kxa[j], kxb[j], 0.f);
+        }
+        va = xx.x; vb = xx.y; vc = xx.z; vd = xx.w;
+        asm volatile("" : "+v"(va), "+v"(vb), "+v"(vc), "+v"(vd));
+    };
+    auto g_pick_c = [&](int u, int e) {                         // channel pair (c0, c0 + 1) at time step e of unit u
+        const float4 A = ga_[u], Bv = gb_[u];
+        va = (e == 0) ? A.x : (e == 1) ? A.y : (e == 2) ? A.z : A.w;
+        vb = (e == 0) ? Bv.x : (e == 1) ? Bv.y : (e == 2) ? Bv.z : Bv.w;
+        asm volatile("" : "+v"(va), "+v"(vb));
+    };
+    auto d_out = [&](int u, int e) {
+        const bf16x2 la = {(__bf16)va, (__bf16)vb};
+        unsigned* D32 = reinterpret_cast<unsigned*>(Db);
+        const int o = (1 + 4 * (q0 + 8 * u) + e) * (PITCH / 2) + cp;
+        D32[o] = p0; D32[(ROWS * PITCH >> 1) + o] = p1; D32[2 * (ROWS * PITCH >> 1) + o] = __builtin_bit_cast(unsigned, la);
+    };
+    // halos: the gradient's for image D (rows 0 and 65), the input operand's for image X' (elements XO - 1, XO + 64)
+    auto hx_pick = [&]() {
+        float v = hxv;
+        if (XPRO == PRO_BNRELU) v = pro_apply<PRO_BNRELU>(v, 0.f, hxa, hxb, 0.f);
+        va = okh_cur ? v : 0.f; vb = 0.f;
+        asm volatile("" : "+v"(va), "+v"(vb));
+    };
+    auto hx_out = [&](unsigned short* X) {
+        const bf16x2 la = {(__bf16)va, (__bf16)vb};
+        if (tid < 128) {
+            const int o = hc * PX + (hh ? XO + NT : XO - 1);
+            X[o] = (unsigned short)p0; X[64 * PX + o] = (unsigned short)p1; X[2 * 64 * PX + o] = (unsigned short)__builtin_bit_cast(unsigned, la);
+        }
+    };
+    auto hg_pick = [&]() {
+        const float v = pro_apply<PRO_BNBWD>(hg, hy, hga, hgb, hgc, hgl);
+        va = okh_cur ? v : 0.f; vb = 0.f;
+        asm volatile("" : "+v"(va), "+v"(vb));
+    };
+    auto hg_out = [&]() {
+        const bf16x2 la = {(__bf16)va, (__bf16)vb};
+        if (tid < 128) {
+            const int o = (hh ? NT + 1 : 0) * PITCH + hc;
+            Db[o] = (unsigned short)p0; Db[ROWS * PITCH + o] = (unsigned short)p1; Db[2 * ROWS * PITCH + o] = (unsigned short)__builtin_bit_cast(unsigned, la);
+        }
+    };
+    // phase-A side work, slice v of 56: the operands in the registers -> images G', X' (rebuild + time-pair split)
+    //   v 0..27  gradient: per (unit, channel) 7 slices: build a | build b | pick | hi a | mid a + hi b | mid b | lo + write
+    //   v 28..51 input:    per (unit, channel) 6 slices: pick (+ BN + ReLU) | hi a | mid a | hi b | mid b | lo + write
+    //   v 52..55 input halo
+    auto sideA = [&](int v, unsigned short* G, unsigned short* X) __attribute__((always_inline)) {
+        if (v < 28) {
+            const int uj = v / 7, st = v % 7, u = uj >> 1, j = uj & 1;
+            if (st == 0) g_build(u, j, 0);
+            if (st == 1) g_build(u, j, 1);
+            if (st == 2) { g_pick_t(u, j); if (j == 1) load_g(u); }          // both channels of the unit rebuilt: refill its raw registers
+            if (st == 3) s1a();
+            if (st == 4) { s2a(); s1b(); }
+            if (st == 5) s2b();
+            if (st == 6) out4(G + (c0 + j) * PG + 4 * (q0 + 8 * u), 64 * PG);
+        } else if (v < 52) {
+            const int w = v - 28, uj = w / 6, st = w % 6, u = uj >> 1, j = uj & 1;
+            if (st == 0) x_pick_t(u, j);
+            if (st == 1) { s1a(); if (j == 1) load_x(u); }
+            if (st == 2) s2a();
+            if (st == 3) s1b();
+            if (st == 4) s2b();
+            if (st == 5) out4(X + (c0 + j) * PX + XO + 4 * (q0 + 8 * u), 64 * PX);
+        } else {
+            const int st = v - 52;
+            if (st == 0) { hx_pick(); load_xhalo(); }
+            if (st == 1) s1a();
+            if (st == 2) s2a();
+            if (st == 3) hx_out(X);
+        }
+    };
+    // phase-B side work, slice v of 36: the rebuilt gradient -> image D (channel-pair split), then the refill
+    //   v 0..31  per (unit, time step) 4 slices: pick | hi | mid | lo + write;   v 32..35 gradient halo
+    auto sideB = [&](int v) __attribute__((always_inline)) {
+        if (v < 32) {
+            const int ue = v >> 2, st = v & 3, u = ue >> 2, e = ue & 3;
+            if (st == 0) g_pick_c(u, e);
+            if (st == 1) s1a();
+            if (st == 2) s2a();
+            if (st == 3) d_out(u, e);
+        } else {
+            const int st = v - 32;
+            if (st == 0) { hg_pick(); load_ghalo(); }
+            if (st == 1) s1a();
+            if (st == 2) s2a();
+            if (st == 3) hg_out();
+        }
+    };
+    {   // first tile: all images serially; the refills inside the slices already fetch the second tile
+        set_tile(min(tile + tstep, ntiles - 1));
+        const bool okh_n = okh;
+#pragma unroll
+        for (int v = 0; v < 56; ++v) sideA(v, Gb0, Xb0);
+#pragma unroll
+        for (int v = 0; v < 36; ++v) sideB(v);
+        okh_cur = okh_n;
+    }
+    __syncthreads();
+
+    f32x16 wacc[KW];
+#pragma unroll
+    for (int k = 0; k < KW; ++k)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) wacc[k][r] = 0.f;
+    float s1[STATS ? 16 : 1], s2[STATS ? 16 : 1];
+    if (STATS) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+    }
+    float e1r[16];
+    int buf = 0;
+#define FENCE __builtin_amdgcn_sched_barrier(0)
+    while (tile < ntiles) {
+        // registers: the raw operands of tile + tstep (clamped: the duplicate of the last tile is split but never used)
+        const int b = tile / tilesPerClip, t0 = (tile - b * tilesPerClip) * NT;
+        bflag = (tile + tstep < ntiles) ? 1.f : 0.f;
+        set_tile(min(tile + 2 * tstep, ntiles - 1));       // what the refills inside the slices fetch
+        const bool okh_n = okh;
+        const unsigned short* Gc = Gb0 + buf * GIMG;
+        const unsigned short* Xc = Xb0 + buf * XIMG;
+        unsigned short* Gn = Gb0 + (buf ^ 1) * GIMG;
+        unsigned short* Xn = Xb0 + (buf ^ 1) * XIMG;
+        // data-gradient output / epilogue operand of this lane: rows 32 mt + (r & 3) + 8 (r >> 2) + 4 half, column t0 + 32 nh + l31
+        const size_t slab = ((size_t)b * 64 + 32 * mt) * T;
+        const wm_srd_t sye = make_srd(a.y + slab, (size_t)32 * T * sizeof(float));
+        const wm_srd_t se1 = make_srd(a.e1 + slab, (size_t)32 * T * sizeof(float));
+        const unsigned eoff = (unsigned)(4 * half * T + t0 + 32 * nh + l31) * 4u;
+        auto roff = [&](int r) { return (unsigned)(((r & 3) + 8 * (r >> 2)) * T) * 4u; };
+
+        // ---------------- phase A: data gradient out of image D
+        f32x16 dacc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dacc[r] = 0.f;
+        {
+            const unsigned short* drow = Db + (32 * nh + l31) * PITCH + 8 * half;
+            bf16x8 Bq[2][NP];
+#pragma unroll
+            for (int p = 0; p < NP; ++p) Bq[0][p] = *reinterpret_cast<const bf16x8*>(drow + p * ROWS * PITCH);
+#pragma unroll
+            for (int s = 0; s < 12; ++s) {
+                if (s + 1 < 12) {
+#pragma unroll
+                    for (int p = 0; p < NP; ++p)
+                        Bq[(s + 1) & 1][p] = *reinterpret_cast<const bf16x8*>(drow + (p * ROWS + ((s + 1) >> 2)) * PITCH + 16 * ((s + 1) & 3));
+                }
+                const bf16x8* Bf = Bq[s & 1];
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    const int pa = (j == 0 || j == 4) ? 1 : (j == 2 ? 2 : 0), pb = (j == 0 || j == 3) ? 1 : (j == 1 ? 2 : 0);
+                    FENCE;
+                    dacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wr[s][pa], Bf[pb], dacc, 0, 0, 0);
+                    FENCE;
+                    const int m = s * 6 + j;                         // 0..71
+                    if (m < 56) sideA(m, Gn, Xn);
+                    else e1r[m - 56] = buf_load(se1, eoff, roff(m - 56));
+                    FENCE;
+                }
+            }
+        }
+        lds_barrier();          // every wave is done with image D; images G', X' of the next tile are complete
+        // ---------------- phase B: weight gradient out of images G', X'; image D of the next tile, epilogue of this one
+        {
+            const int e0 = 8 * half;
+            bf16x8 A[2][NP];
+            uint4 f[2][NP];
+            unsigned Lw[2][NP], Rw[2][NP];
+            bf16x8 Bl[NP], Br[NP];
+            auto read_kb = [&](int kb, int set) {
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    A[set][p] = *reinterpret_cast<const bf16x8*>(Gc + (p * 64 + mt * 32 + l31) * PG + kb * 16 + e0);
+                    const unsigned short* xr = Xc + (p * 64 + nh * 32 + l31) * PX + XO + kb * 16 + e0;
+                    f[set][p] = *reinterpret_cast<const uint4*>(xr);
+                    Lw[set][p] = *reinterpret_cast<const unsigned*>(xr - 2);
+                    Rw[set][p] = *reinterpret_cast<const unsigned*>(xr + 8);
+                }
+            };
+            auto shl = [&](int set, int p) {
+                const uint4 g = f[set][p];
+                uint4 s_ = make_uint4(__builtin_amdgcn_alignbit(g.x, Lw[set][p], 16), __builtin_amdgcn_alignbit(g.y, g.x, 16),
+                                      __builtin_amdgcn_alignbit(g.z, g.y, 16), __builtin_amdgcn_alignbit(g.w, g.z, 16));
+                asm volatile("" : "+v"(s_.x), "+v"(s_.y), "+v"(s_.z), "+v"(s_.w));
+                Bl[p] = __builtin_bit_cast(bf16x8, s_);
+            };
+            auto shr = [&](int set, int p) {
+                const uint4 g = f[set][p];
+                uint4 s_ = make_uint4(__builtin_amdgcn_alignbit(g.y, g.x, 16), __builtin_amdgcn_alignbit(g.z, g.y, 16),
+                                      __builtin_amdgcn_alignbit(g.w, g.z, 16), __builtin_amdgcn_alignbit(Rw[set][p], g.w, 16));
+                asm volatile("" : "+v"(s_.x), "+v"(s_.y), "+v"(s_.z), "+v"(s_.w));
+                Br[p] = __builtin_bit_cast(bf16x8, s_);
+            };
+            // epilogue of accumulator row r of the data gradient
+            auto epi = [&](int r) {
+                const int co = 32 * mt + mfma_row(r, half);
+                float v = dacc[r];
+                if (EPI == EPI_RELUMASK) {
+                    const float qv = e1r[r];
+                    v = (fmaf(qv, Cs[384 + co], Cs[448 + co]) > 0.f) ? v : 0.f;
+                    s1[r] += v; s2[r] = fmaf(v, qv, s2[r]);
+                    asm volatile("" : "+v"(s1[r]), "+v"(s2[r]));
+                } else {
+                    v += e1r[r];
+                }
+                buf_store(sye, v, eoff, roff(r));
+            };
+            read_kb(0, 0);
+#pragma unroll
+            for (int m = 0; m < 72; ++m) {
+                const int kb = m / 18, tg = (m % 18) / 6, j = m % 6, set = kb & 1;
+                const int pa = (j == 0 || j == 4) ? 1 : (j == 2 ? 2 : 0), pb = (j == 0 || j == 3) ? 1 : (j == 1 ? 2 : 0);
+                FENCE;
+                if (tg == 0)
+                    wacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[set][pa], __builtin_bit_cast(bf16x8, f[set][pb]), wacc[1], 0, 0, 0);
+                else if (tg == 1)
+                    wacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[set][pa], Bl[pb], wacc[0], 0, 0, 0);
+                else
+                    wacc[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[set][pa], Br[pb], wacc[2], 0, 0, 0);
+                FENCE;
+                // ---- the slice behind MFMA m: 18 per k-block
+                const int mm = m % 18;
+                if (mm < 3) shl(set, mm);
+                else if (mm < 6) shr(set, mm - 3);
+                else {
+                    const int v = kb * 12 + (mm - 6);             // 0..47
+                    if (v < 36) sideB(v);
+                    else if (v < 44) { epi(2 * (v - 36)); epi(2 * (v - 36) + 1); }
+                }
+                if (mm == 12 && kb + 1 < 4) read_kb(kb + 1, set ^ 1);
+                FENCE;
+            }
+            okh_cur = okh_n;
+        }
+        lds_barrier();          // image D of the next tile is complete; images G', X' of this tile are free
+        tile += tstep;
+        buf ^= 1;
+    }
+#undef FENCE
+
+    // ---- outputs: weight-gradient slab (every wave owns its block), bias sums, BatchNorm sums of the data gradient
+    float* out = a.partial + (size_t)blockIdx.x * (KW * 4096 + 64);
+#pragma unroll
+    for (int k = 0; k < KW; ++k)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) out[(k * 64 + mt * 32 + mfma_row(r, half)) * 64 + nh * 32 + l31] = wacc[k][r];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {       // the eight lanes of a channel pair sit 8 apart
+        float v = bsum[j];
+        v += __shfl_xor(v, 8); v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+        if (lane < 8) out[KW * 4096 + c0 + j] = v;
+    }
+    if (STATS) {
+        float* red = reinterpret_cast<float*>(smem_raw);          // [2 column halves][2][64]
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { s1[j] = half_wave_sum(s1[j]); s2[j] = half_wave_sum(s2[j]); }
+        __syncthreads();
+        if (l31 == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = 32 * mt + mfma_row(r, half);
+                red[nh * 128 + co] = s1[r];
+                red[nh * 128 + 64 + co] = s2[r];
+            }
+        }
+        __syncthreads();
+        if (tid < 128) a.stats[(size_t)blockIdx.x * 128 + tid] = red[tid] + red[128 + tid];
+    }
+}
+
+template <int EPI, int XPRO>
+int launch_dwgrad64bf(const DWArgs& a, int* grid_out, hipStream_t stream) {
+    constexpr size_t lds = (size_t)(3 * 66 * 72 + 2 * 3 * 64 * 72 + 2 * 3 * 64 * 88) * 2 + 8 * 64 * sizeof(float);
+    static wm::DevOnce attr_done;
+    auto kern = dwgrad64bf_kernel<EPI, XPRO>;
+    if (!wm::dev_done(attr_done)) {
+        WM_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        wm::dev_mark(attr_done);
+    }
+    const int ntiles = a.B * (a.T / 64);
+    const int grid = ntiles < kNumCU ? ntiles : kNumCU;
+    *grid_out = grid;
+    if (a.stats && grid < kNumCU) WM_TRY(hipMemsetAsync(a.stats, 0, sizeof(float) * 128 * kNumCU, stream));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, a);
+    WM_CHECK_LAUNCH();
+    return 0;
+}
+
 }  // namespace
 
 // =============================================================================================
@@ -3050,6 +3515,25 @@ int wm_wgrad64_bf(const float* g, const float* g2, const float* ga, const float*
         rc = small ? launch_wgrad64bf_small<PRO_BNBWD, PRO_NONE>(a, &grid, stream) : launch_wgrad64bf<PRO_BNBWD, PRO_NONE>(a, &grid, stream);
     else if (gpro == PRO_NONE && xpro == PRO_NONE)            // main14b_2's 64-channel blocks: both operands as they are
         rc = launch_wgrad64bf<PRO_NONE, PRO_NONE>(a, &grid, stream);
+    if (rc) return rc;
+    const int n = 3 * 4096 + 64;
+    hipLaunchKernelGGL(wgrad64_reduce_kernel, dim3((n + 63) / 64), dim3(256), 0, stream, (const float*)partial, grid, 3, 0, dw,
+                       dbias, accumulate & 1);
+    WM_CHECK_LAUNCH();
+    return 0;
+}
+
+// data gradient + weight gradient of a k3 convolution in one launch (dwgrad64bf_kernel); T % 64 == 0
+int wm_dwgrad64_bf(const float* g, const float* g2, const float* ga, const float* gb, const float* gc, const void* wpb,
+                   const float* x, const float* xa, const float* xb, const float* e1, const float* ea, const float* eb,
+                   float* y, float* stats, float* partial, float* dw, float* dbias, int B, int T, int xpro, int epi, int accumulate,
+                   hipStream_t stream) {
+    if (B <= 0 || T <= 0 || (T & 63)) return (int)hipErrorInvalidValue;
+    if (!g || !g2 || !ga || !gb || !gc || !wpb || !x || !e1 || !y || !partial || !dw) return (int)hipErrorInvalidValue;
+    DWArgs a{g, g2, ga, gb, gc, wpb, x, xa, xb, e1, ea, eb, y, stats, partial, B, T};
+    int grid = 0, rc = (int)hipErrorInvalidValue;
+    if (epi == EPI_RELUMASK && xpro == PRO_BNRELU && stats && xa && xb && ea && eb) rc = launch_dwgrad64bf<EPI_RELUMASK, PRO_BNRELU>(a, &grid, stream);
+    else if (epi == EPI_ADD && xpro == PRO_NONE && !stats) rc = launch_dwgrad64bf<EPI_ADD, PRO_NONE>(a, &grid, stream);
     if (rc) return rc;
     const int n = 3 * 4096 + 64;
     hipLaunchKernelGGL(wgrad64_reduce_kernel, dim3((n + 63) / 64), dim3(256), 0, stream, (const float*)partial, grid, 3, 0, dw,

@@ -146,7 +146,8 @@ def _on_side(inputs, fn, defer=True):
 # bf16 matrix cores, see csrc/conv64.hip).  WM_CONV_BF16X6=0/1 in the environment overrides the default.
 import os as _os
 _CONV = {"bf16x6": _os.environ.get("WM_CONV_BF16X6", "1") == "1", "schedule": 2,
-         "one_launch_eval": _os.environ.get("WM_RESBLOCK_ONE_LAUNCH", "1") == "1"}
+         "one_launch_eval": _os.environ.get("WM_RESBLOCK_ONE_LAUNCH", "1") == "1",
+         "fused_bwd": _os.environ.get("WM_FUSED_BWD", "1") == "1"}
 
 
 def set_conv_bf_schedule(schedule: int):
@@ -161,6 +162,12 @@ if "WM_CONV_BF_SCHEDULE" in _os.environ:
 
 def set_conv_bf16x6(on: bool):
     _CONV["bf16x6"] = bool(on)
+
+
+def set_fused_backward(on: bool):
+    """ResBlock backward: data gradient + weight gradient of each convolution in ONE launch (wm_dwgrad64_bf, default) or as two
+    (wm_conv64_bf + wm_wgrad64_bf).  WM_FUSED_BWD=0/1 in the environment sets the default."""
+    _CONV["fused_bwd"] = bool(on)
 
 
 def set_resblock_one_launch(on: bool):
@@ -273,9 +280,22 @@ class ResBlockFn(GradAwareFunction):
         # conv2: data gradient (+ ReLU mask + BN1-backward reductions in the epilogue) and weight gradient
         dz1 = torch.empty_like(x)
         stats = _f32(NCU * 128, device=dev)
-        _conv3(dz2, y2, w2, 1, k2[0], k2[1], k2[3], None, y1, sc1, sh1, dz1, stats, B, T, 3, 1)
         gw1, gb1, gw2, gb2 = ctx.gdst
         side = all(g is not None for g in ctx.gdst)
+        if _CONV["bf16x6"] and _CONV["fused_bwd"] and not side and T % 64 == 0:
+            # data gradient AND weight gradient of each convolution in one launch: the gradient frames are read once
+            dw2, db2, dw1, db1 = torch.empty_like(w2), _f32(64, device=dev), torch.empty_like(w1), _f32(64, device=dev)
+            wpart = _f32(NCU * (3 * 4096 + 64), device=dev)
+            lib.wm_dwgrad64_bf(_p(dz2), _p(y2), _p(k2[0]), _p(k2[1]), _p(k2[3]), _p(pack_w64_bf(w2, 1)), _p(y1), _p(sc1), _p(sh1),
+                               _p(y1), _p(sc1), _p(sh1), _p(dz1), _p(stats), _p(wpart), _p(dw2), _p(db2), B, T, 1, 1, 0, st)
+            k1 = _f32(4, 64, device=dev)
+            dg1, dbe1 = _f32(64, device=dev), _f32(64, device=dev)
+            lib.wm_bn_bwd_finalize(_p(stats), NCU, n, _p(g1), _p(mu1), _p(is1), _p(k1[0]), _p(k1[1]), _p(k1[3]), _p(dg1), _p(dbe1), 0, ev, st)
+            dx = torch.empty_like(x)
+            lib.wm_dwgrad64_bf(_p(dz1), _p(y1), _p(k1[0]), _p(k1[1]), _p(k1[3]), _p(pack_w64_bf(w1, 1)), _p(x), None, None,
+                               _p(dz2), None, None, _p(dx), None, _p(wpart), _p(dw1), _p(db1), B, T, 0, 2, 0, st)
+            return dx, dw1, db1, dg1, dbe1, dw2, db2, dg2, dbe2, None, None, None, None, None, None, None
+        _conv3(dz2, y2, w2, 1, k2[0], k2[1], k2[3], None, y1, sc1, sh1, dz1, stats, B, T, 3, 1)
 
         def wgrad2():
             wpart = _f32(2 * NCU * (3 * 4096 + 64), device=dev)

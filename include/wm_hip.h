@@ -75,6 +75,18 @@ int wm_pack_w64_bf_scaled(const float* w, const float* row_scale, void* wpb, wm_
 int wm_resblock_eval_bf(const float* x, const void* w1pb, const void* w2pb, const float* b1, const float* sc1, const float* sh1,
                         const float* b2, const float* sc2, const float* sh2, float* y, int B, int T, wm_stream_t stream);
 
+/* Data gradient AND weight gradient of a 64->64 k3 convolution in ONE launch (ResBlock backward, py/main16.py:112-125 under
+ * autograd): g = ga[c] dz + gb[c] + gb[64+c] + gc[c] y is rebuilt once and feeds both; frames moved: 4 (conv2 pair) / 5 (conv1
+ * pair) instead of 7.  wpb = wm_pack_w64_bf mode-1 image.  Two forms:
+ *   xpro 1, epi 1: x' = relu(x xa + xb) is the weight gradient's input operand; y = data gradient masked by (e1 ea + eb > 0),
+ *                  stats [256][2][64] = (sum y, sum y e1) per workgroup (reduce with wm_bn_bwd_finalize)       [conv2 of a block]
+ *   xpro 0, epi 2: x as is; y = data gradient + e1; stats NULL                                                 [conv1 of a block]
+ * dw [out][in][3] / dbias [64] as wm_wgrad64_bf (partial: 256 x (3*4096+64) floats of scratch; accumulate 0 | 1).  T % 64 == 0. */
+int wm_dwgrad64_bf(const float* g, const float* g2, const float* ga, const float* gb, const float* gc, const void* wpb,
+                   const float* x, const float* xa, const float* xb, const float* e1, const float* ea, const float* eb,
+                   float* y, float* stats, float* partial, float* dw, float* dbias, int B, int T, int xpro, int epi, int accumulate,
+                   wm_stream_t stream);
+
 /* bf16x6 build of the 7-tap ConvTranspose1d(64,64,7,padding=3) (py/main16.py:144): wpb [3][7][64][64] uint16 from
  * wm_pack_w64_bf7 (mode 2 forward | 3 data gradient).  pro 0 x | 2 x + vec[b*64+c]; epi 0 + bias[c] | 3 none. */
 int wm_pack_w64_bf7(const float* w, void* wpb, int mode, wm_stream_t stream);

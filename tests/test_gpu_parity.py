@@ -254,7 +254,7 @@ def test_out_of_range_message_raises(awm, dev):
 
 
 @pytest.mark.parametrize("training", [False, True])
-@pytest.mark.parametrize("B,T", [(2, 1000), (1, 256), (3, 1284)])
+@pytest.mark.parametrize("B,T", [(2, 1000), (1, 256), (3, 1284), (3, 640), (2, 16000)])   # T % 64 == 0: the fused data+weight gradient launch
 def test_resblock(awm, dev, training, B, T):
     sd = _resblock_state(10 + B)
     x = rnd(B, 64, T, seed=11).abs() * 0.7        # post-ReLU-like input
