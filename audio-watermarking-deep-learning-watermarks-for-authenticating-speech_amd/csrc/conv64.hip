@@ -1066,15 +1066,24 @@ __global__ __launch_bounds__(256) void conv64bf3_kernel(Conv64Args a) {
     }
     // epilogue of value idx = nt * 16 + r of the previous tile; cb/ct0 = the tile being computed now, whose epilogue
     // operand replaces the consumed one in the same register (it is needed one full iteration from now)
+    // per-row epilogue constants of this lane's 16 accumulator rows, in registers: an LDS read inside an epilogue slice stalls
+    // the wave for the whole LDS latency in front of the next MFMA
+    constexpr bool KB = (EPI == EPI_BIAS || EPI == EPI_BNADDRELU), KE = (EPI == EPI_RELUMASK || EPI == EPI_BNADDRELU);
+    float kbias[KB ? 16 : 1], kea[KE ? 16 : 1], keb[KE ? 16 : 1];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int co = 32 * mt + mfma_row(r, half);
+        if (KB) kbias[r] = Cs[192 + co];
+        if (KE) { kea[r] = Cs[256 + co]; keb[r] = Cs[320 + co]; }
+    }
     auto epi_value = [&](int idx, int cb, int ct0) {
         const int nt = idx >> 4, r = idx & 15;
-        const int co = 32 * mt + mfma_row(r, half);
         float v = accp[nt][r];
         float q = 0.f;
-        if (EPI == EPI_BIAS) v += Cs[192 + co];
-        if (EPI == EPI_RELUMASK) { q = e1r[idx]; v = (fmaf(q, Cs[256 + co], Cs[320 + co]) > 0.f) ? v : 0.f; }
+        if (EPI == EPI_BIAS) v += kbias[r];
+        if (EPI == EPI_RELUMASK) { q = e1r[idx]; v = (fmaf(q, kea[r], keb[r]) > 0.f) ? v : 0.f; }
         if (EPI == EPI_ADD) v += e1r[idx];
-        if (EPI == EPI_BNADDRELU) v = fmaxf(e1r[idx] + fmaf(v + Cs[192 + co], Cs[256 + co], Cs[320 + co]), 0.f);   // = wm_bn_add_relu of the biased conv
+        if (EPI == EPI_BNADDRELU) v = fmaxf(e1r[idx] + fmaf(v + kbias[r], kea[r], keb[r]), 0.f);   // = wm_bn_add_relu of the biased conv
         (a.y + sidx(nt, r))[loff] = v;
         if (STATS) { s1[r] = fmaf(pflag, v, s1[r]); s2[r] = fmaf(pflag * v, (EPI == EPI_RELUMASK) ? q : v, s2[r]); }
 #if WM_BF3_MANUAL
@@ -3180,7 +3189,17 @@ __global__ __launch_bounds__(256) void dwgrad64bf_kernel(DWArgs a) {
         for (int j = 0; j < 16; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
     }
     float e1r[16];
+    // ReLU-mask constants of this lane's 16 accumulator rows, in registers: an LDS read inside an epilogue slice would stall the
+    // wave for the whole LDS latency in front of the next MFMA (measured: +1.3 K cycles per tile)
+    float kea[EPI == EPI_RELUMASK ? 16 : 1], keb[EPI == EPI_RELUMASK ? 16 : 1];
+    if (EPI == EPI_RELUMASK) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { kea[r] = Cs[384 + 32 * mt + mfma_row(r, half)]; keb[r] = Cs[448 + 32 * mt + mfma_row(r, half)]; }
+    }
     int buf = 0;
+#ifdef WM_STAMP
+    unsigned long long tm[6] = {0, 0, 0, 0, 0, 0};
+#endif
 #define FENCE __builtin_amdgcn_sched_barrier(0)
     while (tile < ntiles) {
         // registers: the raw operands of tile + tstep (clamped: the duplicate of the last tile is split but never used)
@@ -3199,6 +3218,7 @@ __global__ __launch_bounds__(256) void dwgrad64bf_kernel(DWArgs a) {
         const unsigned eoff = (unsigned)(4 * half * T + t0 + 32 * nh + l31) * 4u;
         auto roff = [&](int r) { return (unsigned)(((r & 3) + 8 * (r >> 2)) * T) * 4u; };
 
+        STAMP(ts0);
         // ---------------- phase A: data gradient out of image D
         f32x16 dacc;
 #pragma unroll
@@ -3216,20 +3236,32 @@ __global__ __launch_bounds__(256) void dwgrad64bf_kernel(DWArgs a) {
                         Bq[(s + 1) & 1][p] = *reinterpret_cast<const bf16x8*>(drow + (p * ROWS + ((s + 1) >> 2)) * PITCH + 16 * ((s + 1) & 3));
                 }
                 const bf16x8* Bf = Bq[s & 1];
+                // the k-step's three weight fragments as VGPR operands, copied ONCE (most of Wr lives in AGPRs beside the 48 + 16
+                // accumulators; left to itself the compiler re-copies a fragment in front of every MFMA: 262 moves per phase)
+                uint4 wv[NP];
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    wv[p] = __builtin_bit_cast(uint4, Wr[s][p]);
+                    asm volatile("" : "+v"(wv[p].x), "+v"(wv[p].y), "+v"(wv[p].z), "+v"(wv[p].w));
+                }
 #pragma unroll
                 for (int j = 0; j < 6; ++j) {
                     const int pa = (j == 0 || j == 4) ? 1 : (j == 2 ? 2 : 0), pb = (j == 0 || j == 3) ? 1 : (j == 1 ? 2 : 0);
                     FENCE;
-                    dacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wr[s][pa], Bf[pb], dacc, 0, 0, 0);
+                    dacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wv[pa]), Bf[pb], dacc, 0, 0, 0);
                     FENCE;
                     const int m = s * 6 + j;                         // 0..71
+#ifndef DW_SKIP_A
                     if (m < 56) sideA(m, Gn, Xn);
                     else e1r[m - 56] = buf_load(se1, eoff, roff(m - 56));
+#endif
                     FENCE;
                 }
             }
         }
+        STAMP(ts1);
         lds_barrier();          // every wave is done with image D; images G', X' of the next tile are complete
+        STAMP(ts2);
         // ---------------- phase B: weight gradient out of images G', X'; image D of the next tile, epilogue of this one
         {
             const int e0 = 8 * half;
@@ -3263,11 +3295,10 @@ __global__ __launch_bounds__(256) void dwgrad64bf_kernel(DWArgs a) {
             };
             // epilogue of accumulator row r of the data gradient
             auto epi = [&](int r) {
-                const int co = 32 * mt + mfma_row(r, half);
                 float v = dacc[r];
                 if (EPI == EPI_RELUMASK) {
                     const float qv = e1r[r];
-                    v = (fmaf(qv, Cs[384 + co], Cs[448 + co]) > 0.f) ? v : 0.f;
+                    v = (fmaf(qv, kea[r], keb[r]) > 0.f) ? v : 0.f;
                     s1[r] += v; s2[r] = fmaf(v, qv, s2[r]);
                     asm volatile("" : "+v"(s1[r]), "+v"(s2[r]));
                 } else {
@@ -3294,20 +3325,38 @@ __global__ __launch_bounds__(256) void dwgrad64bf_kernel(DWArgs a) {
                 else if (mm < 6) shr(set, mm - 3);
                 else {
                     const int v = kb * 12 + (mm - 6);             // 0..47
+#ifndef DW_SKIP_B
+#ifndef DW_SKIP_DW
                     if (v < 36) sideB(v);
-                    else if (v < 44) { epi(2 * (v - 36)); epi(2 * (v - 36) + 1); }
+#endif
+#ifndef DW_SKIP_EPI
+                    if (v >= 36 && v < 44) { epi(2 * (v - 36)); epi(2 * (v - 36) + 1); }
+#endif
+#endif
                 }
                 if (mm == 12 && kb + 1 < 4) read_kb(kb + 1, set ^ 1);
                 FENCE;
             }
             okh_cur = okh_n;
         }
+        STAMP(ts3);
         lds_barrier();          // image D of the next tile is complete; images G', X' of this tile are free
+        STAMP(ts4);
+#ifdef WM_STAMP
+        tm[0] += ts1 - ts0; tm[1] += ts2 - ts1; tm[2] += ts3 - ts2; tm[3] += ts4 - ts3;
+#endif
         tile += tstep;
         buf ^= 1;
     }
 #undef FENCE
 
+#ifdef WM_STAMP
+    if (g_wm_stamp && lane == 0) {
+        unsigned long long* d = g_wm_stamp + ((size_t)blockIdx.x * 4 + wave) * 6;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) d[i] = tm[i];
+    }
+#endif
     // ---- outputs: weight-gradient slab (every wave owns its block), bias sums, BatchNorm sums of the data gradient
     float* out = a.partial + (size_t)blockIdx.x * (KW * 4096 + 64);
 #pragma unroll
