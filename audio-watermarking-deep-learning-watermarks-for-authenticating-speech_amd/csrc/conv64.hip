@@ -2953,7 +2953,11 @@ __global__ __launch_bounds__(256) void dwgrad64bf_kernel(DWArgs a) {
 #pragma unroll
             for (int p = 0; p < NP; ++p) {
                 const int e = ((p * KW + (s >> 2)) * 64 + 32 * mt + l31) * 64 + 16 * (s & 3) + 8 * half;
-                Wr[s][p] = __builtin_bit_cast(bf16x8, wg[e >> 3]);
+                u32x4 w_ = __builtin_bit_cast(u32x4, wg[e >> 3]);
+                // pinned to the AGPR half of the register file: the MFMA reads its A operand from there directly.  Left to the
+                // allocator the fragments are SPILLED to AGPRs and copied back (v_accvgpr_read) in front of every k-step.
+                asm volatile("" : "+a"(w_));
+                Wr[s][p] = __builtin_bit_cast(bf16x8, w_);
             }
     }
     // ---- staging map: channel pair cp (channels c0, c0 + 1), unit u = time quad q0 + 8 u; halo: channel hc, side hh
@@ -3236,19 +3240,11 @@ __global__ __launch_bounds__(256) void dwgrad64bf_kernel(DWArgs a) {
                         Bq[(s + 1) & 1][p] = *reinterpret_cast<const bf16x8*>(drow + (p * ROWS + ((s + 1) >> 2)) * PITCH + 16 * ((s + 1) & 3));
                 }
                 const bf16x8* Bf = Bq[s & 1];
-                // the k-step's three weight fragments as VGPR operands, copied ONCE (most of Wr lives in AGPRs beside the 48 + 16
-                // accumulators; left to itself the compiler re-copies a fragment in front of every MFMA: 262 moves per phase)
-                uint4 wv[NP];
-#pragma unroll
-                for (int p = 0; p < NP; ++p) {
-                    wv[p] = __builtin_bit_cast(uint4, Wr[s][p]);
-                    asm volatile("" : "+v"(wv[p].x), "+v"(wv[p].y), "+v"(wv[p].z), "+v"(wv[p].w));
-                }
 #pragma unroll
                 for (int j = 0; j < 6; ++j) {
                     const int pa = (j == 0 || j == 4) ? 1 : (j == 2 ? 2 : 0), pb = (j == 0 || j == 3) ? 1 : (j == 1 ? 2 : 0);
                     FENCE;
-                    dacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wv[pa]), Bf[pb], dacc, 0, 0, 0);
+                    dacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wr[s][pa], Bf[pb], dacc, 0, 0, 0);
                     FENCE;
                     const int m = s * 6 + j;                         // 0..71
 #ifndef DW_SKIP_A
