@@ -1324,8 +1324,12 @@ __global__ __launch_bounds__(256) void resblock_eval_kernel(RbeArgs a) {
 #pragma unroll
             for (int p = 0; p < NP; ++p) {
                 const int e = ((p * KW + (s >> 2)) * 64 + 32 * mt + l31) * 64 + 16 * (s & 3) + 8 * half;
+                // the second convolution's fragments are pinned into AGPRs (the MFMA reads its A operand from there in place):
+                // 288 fragment registers do not fit the 256 VGPRs, and fragments the allocator spills are copied back per use
+                u32x4 w2_ = __builtin_bit_cast(u32x4, wg2[e >> 3]);
+                asm volatile("" : "+a"(w2_));
                 W1[s][p] = __builtin_bit_cast(bf16x8, wg1[e >> 3]);
-                W2[s][p] = __builtin_bit_cast(bf16x8, wg2[e >> 3]);
+                W2[s][p] = __builtin_bit_cast(bf16x8, w2_);
             }
     }
     // staging map (fixed per thread): channel pair cp, time quads q0 + 8 i
@@ -1777,7 +1781,9 @@ __global__ __launch_bounds__(256) void conv64bf7p_kernel(Conv64Args a) {
 #pragma unroll
             for (int p = 0; p < NP; ++p) {
                 const int e = ((p * KW + (s >> 2)) * 64 + 32 * mt + l31) * 64 + 16 * (s & 3) + 8 * half;
-                Wr[s][p] = __builtin_bit_cast(bf16x8, wg[e >> 3]);
+                u32x4 w_ = __builtin_bit_cast(u32x4, wg[e >> 3]);
+                if (s >= 8) asm volatile("" : "+a"(w_));      // 336 fragment registers: all but the first 8 k-steps pinned into AGPRs,
+                Wr[s][p] = __builtin_bit_cast(bf16x8, w_);     // where the MFMA reads them in place (no spill / copy-back traffic)
             }
     }
     // ---- staging map (fixed per thread): channel pair cp, time quads q0 + 8 i; halo element k: channel hcn[k], image row hr[k]
