@@ -329,6 +329,8 @@ def main():
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
+            if backend == "gloo":
+                os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")      # single-node rehearsal: no hostname lookup
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     import awm_amd

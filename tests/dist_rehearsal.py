@@ -20,6 +20,7 @@ sys.path.insert(0, ROOT)
 def main():
     out_dir, n_total, T = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")      # no hostname lookup (it may not resolve on the box)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)

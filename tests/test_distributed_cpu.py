@@ -29,6 +29,7 @@ def _grad_flat(gsd, dsd, s, msg):
 def _worker(rank, world, port, T, out):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")      # no hostname lookup (the container's name may not resolve: minutes of DNS timeouts)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.set_num_threads(2)
     import awm_amd
@@ -91,6 +92,7 @@ class _FlatStore:
 def _gradsync_worker(rank, world, port, out):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")      # no hostname lookup (the container's name may not resolve: minutes of DNS timeouts)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.set_num_threads(1)
     from awm_amd import distributed as wmd
