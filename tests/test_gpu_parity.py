@@ -287,11 +287,72 @@ def test_resblock(awm, dev, training, B, T):
                 assert int(st[k]) == int(v)
 
 
+@pytest.mark.parametrize("B,T", [(1, 64), (2, 128), (3, 640)])
+def test_resblock_backward_fused_vs_two_launches(awm, dev, B, T):
+    """ResBlock backward with each convolution's data + weight gradient in ONE launch (wm_dwgrad64_bf, the default for
+    T % 64 == 0) against the two-launch form (wm_conv64_bf dgrad + wm_wgrad64_bf): same arithmetic, different summation order
+    of the weight gradient only -- single tile, tile seams, several clips."""
+    sd = _resblock_state(31 + B)
+    x = rnd(B, 64, T, seed=41).abs() * 0.7
+    g = rnd(B, 64, T, seed=42)
+    res, calls = {}, []
+    orig = awm.lib.wm_dwgrad64_bf
+
+    def spy(*a):
+        calls.append((a[19], a[20]))                          # xpro, epi
+        return orig(*a)
+    awm.lib.wm_dwgrad64_bf = spy
+    try:
+        for fused in (True, False):
+            awm.ops.set_fused_backward(fused)
+            del calls[:]
+            m = awm.ResBlock(64)
+            m.load_state_dict(sd)
+            m.to(dev).train()
+            xd = x.to(dev).requires_grad_()
+            m(xd).backward(g.to(dev))
+            res[fused] = {"dx": xd.grad.clone(), **{k: p.grad.clone() for k, p in m.named_parameters()}}
+            if awm.ops.conv_bf16x6():
+                assert calls == ([(1, 1), (0, 2)] if fused else []), (fused, calls)
+    finally:
+        awm.lib.wm_dwgrad64_bf = orig
+        awm.ops.set_fused_backward(True)
+    wmax = float(res[False]["block.0.weight"].abs().max())
+    for k in res[True]:
+        if k.endswith("block.0.bias") or k.endswith("block.3.bias"):
+            # exactly-zero true gradient (a bias in front of a batch-statistics BatchNorm): fp32 noise on both sides
+            assert float(res[True][k].abs().max()) <= 1e-3 * wmax + 1e-4 and float(res[False][k].abs().max()) <= 1e-3 * wmax + 1e-4
+            continue
+        check_elementwise(res[True][k], res[False][k].cpu(), f"fused vs two-launch {k}", rtol=1e-5, atol_of_max=3e-6)
+
+
+@pytest.mark.parametrize("B,T", [(1, 4), (2, 1000), (1, 1024), (2, 16000)])
+def test_relu_mask_kernels_bit_exact(awm, dev, B, T):
+    """out and its backward through the one-bit-per-element sign mask (wm_bn_add_relu_mask / wm_relu_bwd_reduce_mask) are
+    bit-identical to the kernels that keep / re-read the output frame -- ragged row lengths included."""
+    lib, p = awm.lib, (lambda t: t.data_ptr())
+    x, y2, g = (rnd(B, 64, T, seed=s_).to(dev) for s_ in (51, 52, 53))
+    sc, sh = (torch.rand(64, generator=torch.Generator().manual_seed(54)) + 0.5).to(dev), rnd(64, seed=55, scale=0.3).to(dev)
+    st = torch.cuda.current_stream().cuda_stream
+    out_a, out_b = torch.empty_like(x), torch.empty_like(x)
+    mask = torch.zeros(B * 64 * 16 * ((T + 1023) // 1024), dtype=torch.int64, device=dev)
+    lib.wm_bn_add_relu(p(x), p(y2), p(sc), p(sh), p(out_a), B, T, st)
+    lib.wm_bn_add_relu_mask(p(x), p(y2), p(sc), p(sh), p(out_b), p(mask), B, T, st)
+    assert torch.equal(out_a, out_b)
+    dz_a, dz_b = torch.empty_like(x), torch.empty_like(x)
+    part_a, part_b = torch.zeros(B * 128, device=dev), torch.zeros(B * 128, device=dev)
+    lib.wm_relu_bwd_reduce(p(g), p(out_a), p(y2), p(dz_a), p(part_a), B, T, st)
+    lib.wm_relu_bwd_reduce_mask(p(g), p(mask), p(y2), p(dz_b), p(part_b), B, T, st)
+    assert torch.equal(dz_a, dz_b) and torch.equal(part_a, part_b)
+    assert torch.equal(dz_a, torch.where(out_a > 0, g, torch.zeros_like(g)))
+
+
 # ------------------------------------------------------------------------------------------ convT + embedding
+@pytest.mark.parametrize("T", [1000, 1280])      # 1280 = a multiple of 128: the register-resident 7-tap kernel (conv64bf7p); 1000: the ragged-length one
 @pytest.mark.parametrize("with_msg", [True, False])
-def test_convT_embed(awm, dev, with_msg):
+def test_convT_embed(awm, dev, with_msg, T):
     from awm_amd import ops
-    B, T = 2, 1000
+    B = 2
     x, w, b = rnd(B, 64, T, seed=20), rnd(64, 64, 7, seed=21, scale=0.05), rnd(64, seed=22, scale=0.1)
     table = rnd(50, 64, seed=23)
     msg = torch.tensor([7, 7]) if with_msg else None      # duplicate rows exercise the scatter-add
