@@ -3062,21 +3062,17 @@ __global__ __launch_bounds__(256) void dwgrad64bf_kernel(DWArgs a) {
         *reinterpret_cast<uint2*>(dst + stride_p) = make_uint2(p1, r1);
         *reinterpret_cast<uint2*>(dst + 2 * stride_p) = make_uint2(__builtin_bit_cast(unsigned, la), __builtin_bit_cast(unsigned, lb));
     };
-    // gradient rebuild of channel j of unit u from the raw staging registers (free for the refill afterwards): two slices
-    auto g_build = [&](int u, int j, int hf) {
+    // gradient rebuild of channel j of unit u from the raw staging registers (free for the refill afterwards): one value per slice
+    // (a slice must stay within the shadow of one MFMA, about seven instructions: a twelve-instruction slice costs its excess in full)
+    auto g_build = [&](int u, int j, int e) {
         const float4 dz = j ? rb_[u] : ra_[u], yy = j ? yb_[u] : ya_[u];
         float4& gz = j ? gb_[u] : ga_[u];
-        if (hf == 0) {
-            gz.x = pro_apply<PRO_BNBWD>(dz.x, yy.x, kga[j], kgb[j], kgc[j], kgl[j]);
-            gz.y = pro_apply<PRO_BNBWD>(dz.y, yy.y, kga[j], kgb[j], kgc[j], kgl[j]);
-            bsum[j] = fmaf(bflag, gz.x + gz.y, bsum[j]);
-            asm volatile("" : "+v"(gz.x), "+v"(gz.y), "+v"(bsum[j]));
-        } else {
-            gz.z = pro_apply<PRO_BNBWD>(dz.z, yy.z, kga[j], kgb[j], kgc[j], kgl[j]);
-            gz.w = pro_apply<PRO_BNBWD>(dz.w, yy.w, kga[j], kgb[j], kgc[j], kgl[j]);
-            bsum[j] = fmaf(bflag, gz.z + gz.w, bsum[j]);
-            asm volatile("" : "+v"(gz.z), "+v"(gz.w), "+v"(bsum[j]));
-        }
+        const float d = (e == 0) ? dz.x : (e == 1) ? dz.y : (e == 2) ? dz.z : dz.w;
+        const float yv = (e == 0) ? yy.x : (e == 1) ? yy.y : (e == 2) ? yy.z : yy.w;
+        float v = pro_apply<PRO_BNBWD>(d, yv, kga[j], kgb[j], kgc[j], kgl[j]);
+        bsum[j] = fmaf(bflag, v, bsum[j]);
+        asm volatile("" : "+v"(v), "+v"(bsum[j]));
+        if (e == 0) gz.x = v; else if (e == 1) gz.y = v; else if (e == 2) gz.z = v; else gz.w = v;
     };
     auto g_pick_t = [&](int u, int j) {                         // time pairs of channel j of unit u
         const float4 gz = j ? gb_[u] : ga_[u];
@@ -3130,22 +3126,22 @@ __global__ __launch_bounds__(256) void dwgrad64bf_kernel(DWArgs a) {
             Db[o] = (unsigned short)p0; Db[ROWS * PITCH + o] = (unsigned short)p1; Db[2 * ROWS * PITCH + o] = (unsigned short)__builtin_bit_cast(unsigned, la);
         }
     };
-    // phase-A side work, slice v of 56: the operands in the registers -> images G', X' (rebuild + time-pair split)
-    //   v 0..27  gradient: per (unit, channel) 7 slices: build a | build b | pick | hi a | mid a + hi b | mid b | lo + write
-    //   v 28..51 input:    per (unit, channel) 6 slices: pick (+ BN + ReLU) | hi a | mid a | hi b | mid b | lo + write
-    //   v 52..55 input halo
+    // phase-A side work, slice v of 64 (the other 8 slices fetch the epilogue operand): the operands in the registers -> images G', X'
+    //   v 0..35  gradient: per (unit, channel) 9 slices: rebuild x 4 | pick | hi a | mid a + hi b | mid b | lo + write
+    //   v 36..59 input:    per (unit, channel) 6 slices: pick (+ BN + ReLU) | hi a | mid a | hi b | mid b | lo + write
+    //   v 60..63 input halo
+    constexpr int NSA = 64;
     auto sideA = [&](int v, unsigned short* G, unsigned short* X) __attribute__((always_inline)) {
-        if (v < 28) {
-            const int uj = v / 7, st = v % 7, u = uj >> 1, j = uj & 1;
-            if (st == 0) g_build(u, j, 0);
-            if (st == 1) g_build(u, j, 1);
-            if (st == 2) { g_pick_t(u, j); if (j == 1) load_g(u); }          // both channels of the unit rebuilt: refill its raw registers
-            if (st == 3) s1a();
-            if (st == 4) { s2a(); s1b(); }
-            if (st == 5) s2b();
-            if (st == 6) out4(G + (c0 + j) * PG + 4 * (q0 + 8 * u), 64 * PG);
-        } else if (v < 52) {
-            const int w = v - 28, uj = w / 6, st = w % 6, u = uj >> 1, j = uj & 1;
+        if (v < 36) {
+            const int uj = v / 9, st = v % 9, u = uj >> 1, j = uj & 1;
+            if (st < 4) g_build(u, j, st);
+            if (st == 4) { g_pick_t(u, j); if (j == 1) load_g(u); }          // both channels of the unit rebuilt: refill its raw registers
+            if (st == 5) s1a();
+            if (st == 6) { s2a(); s1b(); }
+            if (st == 7) s2b();
+            if (st == 8) out4(G + (c0 + j) * PG + 4 * (q0 + 8 * u), 64 * PG);
+        } else if (v < 60) {
+            const int w = v - 36, uj = w / 6, st = w % 6, u = uj >> 1, j = uj & 1;
             if (st == 0) x_pick_t(u, j);
             if (st == 1) { s1a(); if (j == 1) load_x(u); }
             if (st == 2) s2a();
@@ -3153,7 +3149,7 @@ __global__ __launch_bounds__(256) void dwgrad64bf_kernel(DWArgs a) {
             if (st == 4) s2b();
             if (st == 5) out4(X + (c0 + j) * PX + XO + 4 * (q0 + 8 * u), 64 * PX);
         } else {
-            const int st = v - 52;
+            const int st = v - 60;
             if (st == 0) { hx_pick(); load_xhalo(); }
             if (st == 1) s1a();
             if (st == 2) s2a();
@@ -3181,7 +3177,7 @@ __global__ __launch_bounds__(256) void dwgrad64bf_kernel(DWArgs a) {
         set_tile(min(tile + tstep, ntiles - 1));
         const bool okh_n = okh;
 #pragma unroll
-        for (int v = 0; v < 56; ++v) sideA(v, Gb0, Xb0);
+        for (int v = 0; v < NSA; ++v) sideA(v, Gb0, Xb0);
 #pragma unroll
         for (int v = 0; v < 36; ++v) sideB(v);
         okh_cur = okh_n;
@@ -3253,10 +3249,8 @@ __global__ __launch_bounds__(256) void dwgrad64bf_kernel(DWArgs a) {
                     dacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wr[s][pa], Bf[pb], dacc, 0, 0, 0);
                     FENCE;
                     const int m = s * 6 + j;                         // 0..71
-#ifndef DW_SKIP_A
-                    if (m < 56) sideA(m, Gn, Xn);
-                    else e1r[m - 56] = buf_load(se1, eoff, roff(m - 56));
-#endif
+                    if (m < NSA) sideA(m, Gn, Xn);
+                    else { e1r[2 * (m - NSA)] = buf_load(se1, eoff, roff(2 * (m - NSA))); e1r[2 * (m - NSA) + 1] = buf_load(se1, eoff, roff(2 * (m - NSA) + 1)); }
                     FENCE;
                 }
             }
@@ -3327,14 +3321,8 @@ __global__ __launch_bounds__(256) void dwgrad64bf_kernel(DWArgs a) {
                 else if (mm < 6) shr(set, mm - 3);
                 else {
                     const int v = kb * 12 + (mm - 6);             // 0..47
-#ifndef DW_SKIP_B
-#ifndef DW_SKIP_DW
                     if (v < 36) sideB(v);
-#endif
-#ifndef DW_SKIP_EPI
-                    if (v >= 36 && v < 44) { epi(2 * (v - 36)); epi(2 * (v - 36) + 1); }
-#endif
-#endif
+                    else if (v < 44) { epi(2 * (v - 36)); epi(2 * (v - 36) + 1); }
                 }
                 if (mm == 12 && kb + 1 < 4) read_kb(kb + 1, set ^ 1);
                 FENCE;
