@@ -31,6 +31,8 @@ def load_best(model, path, map_location="cpu"):
 
 def save_resumable(path, epoch, step, best_val, generator, detector, optimizer=None, scheduler=None):
     """py/main14d.py:540-558 layout"""
+    from . import ops
+    ops.check_message_ids()          # a deferred message-id check must not outlive the weights it would have corrupted
     ck = {"epoch": epoch, "step": step, "best_val": best_val, "gen": generator.state_dict(), "det": detector.state_dict(),
           "opt": _opt_state(optimizer), "sched": scheduler.state_dict() if scheduler is not None else None}
     tmp = path + ".tmp"
@@ -51,15 +53,14 @@ def load_resumable(path, generator, detector, optimizer=None, scheduler=None, ma
 
 
 def _opt_state(opt):
-    """`optimizer.state_dict()` (py/main14d.py:547): optim.FlatAdam emits torch.optim.Adam's layout, tensors on the CPU"""
+    """`optimizer.state_dict()` (py/main14d.py:547) with its tensors copied to the CPU.  torch.optim's state_dict() hands out
+    the LIVE per-parameter dicts (`sd["state"][i] is opt.state[p]`), so the copy is built from new dicts -- writing the CPU
+    tensors into the returned ones would move a running torch.optim.Adam's moments off the GPU."""
     if opt is None:
         return None
     sd = opt.state_dict()
-    for st in sd.get("state", {}).values():
-        for k, v in st.items():
-            if torch.is_tensor(v):
-                st[k] = v.detach().cpu()
-    return sd
+    state = {i: {k: (v.detach().cpu() if torch.is_tensor(v) else v) for k, v in st.items()} for i, st in sd.get("state", {}).items()}
+    return {"state": state, "param_groups": [dict(g) for g in sd.get("param_groups", [])]}
 
 
 def _load_opt_state(opt, state):

@@ -99,8 +99,21 @@ class GradSync:
     def enabled(self):
         return self.force or _active()
 
+    def begin_step(self):
+        """re-arm for a new backward (train_step calls it with zero_grad): a backward whose __call__ never ran -- an exception
+        between the two, or a second backward -- must not leave its collective or its hook count behind"""
+        if self._work is not None:
+            self._work.wait()
+            if self._side is not None:
+                torch.cuda.current_stream().wait_stream(self._side)
+            self._work = None
+        self._pending = self._n_early
+
     def _on_accumulated(self, _param):
         self._pending -= 1
+        if self._pending < 0 or (self._pending == 0 and self._work is not None):
+            raise RuntimeError("GradSync: a second backward reached the early-span hooks before the first one was exchanged "
+                               "(call the GradSync object after every backward, or begin_step() to discard one)")
         if self._pending == 0 and self.enabled():
             self._launch_early()
 

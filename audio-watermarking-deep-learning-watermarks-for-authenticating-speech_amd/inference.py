@@ -28,26 +28,101 @@ def load_audio(file_path, sample_rate=SAMPLE_RATE):
             waveform = torchaudio.transforms.Resample(sr, sample_rate)(waveform)
         return waveform
     except ImportError:
-        with wave.open(file_path, "rb") as w:
-            if w.getsampwidth() != 2:
-                raise ValueError("without torchaudio only 16-bit PCM wav files can be read")
-            if w.getframerate() != sample_rate:
-                raise ValueError(f"without torchaudio no resampling is available (file is {w.getframerate()} Hz)")
-            data = np.frombuffer(w.readframes(w.getnframes()), dtype="<i2").astype(np.float32) / 32768.0
-            data = data.reshape(-1, w.getnchannels()).mean(axis=1)
-        return torch.from_numpy(data.copy()).unsqueeze(0)
+        data, rate = _read_wav(file_path)
+        if rate != sample_rate:
+            raise ValueError(f"without torchaudio no resampling is available (file is {rate} Hz)")
+        return torch.from_numpy(data.mean(axis=1).astype(np.float32)).unsqueeze(0)
 
 
-def save_audio(file_path, waveform, sample_rate=SAMPLE_RATE):
-    """16-bit PCM wav (what torchaudio.save writes for the reference's float input by default is float; the int16 path
-    of py/main15.py:850-867 is the portable one and needs no torchaudio)."""
-    out_dir = os.path.dirname(file_path)
+def _read_wav(path):
+    """RIFF/WAVE reader for the two encodings this package writes: 16-bit signed PCM (format 1, scaled by 1/32768 as
+    torchaudio.load normalises it) and 32-bit IEEE float (format 3).  Returns ((frames, channels) float32, sample rate)."""
+    import struct
+    with open(path, "rb") as f:
+        blob = f.read()
+    if blob[:4] != b"RIFF" or blob[8:12] != b"WAVE":
+        raise ValueError(f"{path}: not a RIFF/WAVE file")
+    pos, fmt, data = 12, None, None
+    while pos + 8 <= len(blob):
+        tag, size = blob[pos:pos + 4], struct.unpack("<I", blob[pos + 4:pos + 8])[0]
+        body = blob[pos + 8:pos + 8 + size]
+        if tag == b"fmt ":
+            fmt = struct.unpack("<HHIIHH", body[:16])
+        elif tag == b"data":
+            data = body
+        pos += 8 + size + (size & 1)
+    if fmt is None or data is None:
+        raise ValueError(f"{path}: missing fmt or data chunk")
+    code, channels, rate, _, _, bits = fmt
+    if code == 1 and bits == 16:
+        x = np.frombuffer(data, dtype="<i2").astype(np.float32) / 32768.0
+    elif code == 3 and bits == 32:
+        x = np.frombuffer(data, dtype="<f4").astype(np.float32)
+    else:
+        raise ValueError("without torchaudio only 16-bit PCM and 32-bit float wav files can be read")
+    return x.reshape(-1, channels), rate
+
+
+def save_audio_float(waveform, output_path, sample_rate=SAMPLE_RATE):
+    """py/main16.py:802-804 / :1051-1055: `torchaudio.save(path, float_waveform, sample_rate)` stores a float tensor as a
+    32-bit IEEE-float WAV (samples bit for bit).  Written here as a plain RIFF file (format tag 3)."""
+    import struct
+    out_dir = os.path.dirname(output_path)
     if out_dir:
         os.makedirs(out_dir, exist_ok=True)
-    pcm = (waveform.detach().cpu().clamp(-1, 1) * 32767.0).round().to(torch.int16).numpy().reshape(-1)
-    with wave.open(file_path, "wb") as w:
-        w.setnchannels(1); w.setsampwidth(2); w.setframerate(sample_rate)
-        w.writeframes(pcm.astype("<i2").tobytes())
+    x = waveform.detach().cpu().to(torch.float32)
+    if x.dim() == 1:
+        x = x.unsqueeze(0)
+    ch = x.shape[0]
+    payload = np.ascontiguousarray(x.numpy().T).astype("<f4").tobytes()
+    hdr = (b"RIFF" + struct.pack("<I", 36 + len(payload)) + b"WAVE" + b"fmt " +
+           struct.pack("<IHHIIHH", 16, 3, ch, sample_rate, sample_rate * ch * 4, ch * 4, 32) + b"data" + struct.pack("<I", len(payload)))
+    with open(output_path, "wb") as f:
+        f.write(hdr + payload)
+
+
+def lowpass_biquad(waveform, sample_rate, cutoff_freq, Q=0.707):
+    """torchaudio.functional.lowpass_biquad (imported at py/main15.py:18, called at :855), restated from its published
+    definition: the RBJ cookbook low-pass section  b = ((1-cos w0)/2, 1-cos w0, (1-cos w0)/2),  a = (1+alpha, -2 cos w0, 1-alpha)
+    with w0 = 2 pi cutoff / sample_rate and alpha = sin w0 / (2 Q), normalised by a0, run along the last axis as an IIR filter
+    in the waveform's dtype, and the output clamped to [-1, 1] (torchaudio's `lfilter(..., clamp=True)` default).
+    PARITY UNPINNED: torchaudio is absent from this image and the reference holds no fixture of this function; the order of
+    the fp32 additions inside torchaudio's lfilter (direct form I) is not reproduced bit for bit -- scipy's lfilter
+    (transposed direct form II) carries the recursion here."""
+    from scipy.signal import lfilter
+    w0 = 2.0 * math.pi * float(cutoff_freq) / float(sample_rate)
+    alpha = math.sin(w0) / (2.0 * float(Q))
+    cw = math.cos(w0)
+    b = np.array([(1.0 - cw) / 2.0, 1.0 - cw, (1.0 - cw) / 2.0], dtype=np.float64)
+    a = np.array([1.0 + alpha, -2.0 * cw, 1.0 - alpha], dtype=np.float64)
+    x = waveform.detach().cpu()
+    y = lfilter((b / a[0]).astype(np.float32), (a / a[0]).astype(np.float32), x.to(torch.float32).numpy(), axis=-1)
+    return torch.from_numpy(np.ascontiguousarray(y, dtype=np.float32)).clamp_(-1.0, 1.0).to(x.dtype)
+
+
+def pcm16(waveform):
+    """float waveform -> signed 16-bit PCM exactly as py/main15.py:858: clamp to [-1, 1], scale by 32767, and the
+    TRUNCATING float -> int16 conversion of `.to(torch.int16)` (toward zero; no rounding)."""
+    return (waveform.detach().cpu().clamp(-1.0, 1.0) * 32767).to(torch.int16)
+
+
+def save_audio(waveform, output_path, sample_rate=SAMPLE_RATE, lowpass_hz=7000):
+    """py/main15.py:850-867 `save_audio(waveform, output_path, sample_rate)`: 7 kHz biquad low-pass -> clamp -> x32767 ->
+    truncating int16 cast -> 16-bit signed PCM WAV.  The container is written with the standard library (`torchaudio.save(...,
+    encoding="PCM_S", bits_per_sample=16)` in the reference; a mono or (C, N) waveform, samples interleaved by channel).
+    `lowpass_hz=None` skips the filter (the PCM bytes are then exactly pcm16(waveform))."""
+    out_dir = os.path.dirname(output_path)
+    if out_dir:
+        os.makedirs(out_dir, exist_ok=True)
+    x = waveform.detach().cpu()
+    if x.dim() == 1:
+        x = x.unsqueeze(0)
+    if lowpass_hz is not None:
+        x = lowpass_biquad(x, sample_rate, cutoff_freq=lowpass_hz)
+    pcm = pcm16(x).numpy()                                   # (C, N)
+    with wave.open(output_path, "wb") as w:
+        w.setnchannels(pcm.shape[0]); w.setsampwidth(2); w.setframerate(sample_rate)
+        w.writeframes(np.ascontiguousarray(pcm.T).astype("<i2").tobytes())
 
 
 def _segments(waveform, seg_len=SAMPLE_RATE):
@@ -62,15 +137,20 @@ def _segments(waveform, seg_len=SAMPLE_RATE):
     return torch.stack(segs, dim=0), remainder
 
 
+def _si_snr_db(ref, est, eps):
+    """scale-invariant SNR in dB along axis 1: both signals centred, `est` split into its projection on `ref` and the rest,
+    10 log10 of the energy ratio (eps added to the projection's denominator and to the residual energy, as py/main16.py:764-773)"""
+    ref = ref - ref.mean(dim=1, keepdim=True)
+    est = est - est.mean(dim=1, keepdim=True)
+    gain = (ref * est).sum(dim=1, keepdim=True) / (ref.pow(2).sum(dim=1, keepdim=True) + eps)
+    proj = gain * ref
+    resid = est - proj
+    return 10 * torch.log10(proj.pow(2).sum(dim=1) / (resid.pow(2).sum(dim=1) + eps))
+
+
 def compute_si_snr(s, s_hat, eps=1e-8):
-    """py/main16.py:764-773"""
-    s = s - s.mean(dim=1, keepdim=True)
-    s_hat = s_hat - s_hat.mean(dim=1, keepdim=True)
-    dot = torch.sum(s * s_hat, dim=1, keepdim=True)
-    alpha = dot / (torch.sum(s ** 2, dim=1, keepdim=True) + eps)
-    s_target = alpha * s
-    e_noise = s_hat - s_target
-    return (10 * torch.log10(torch.sum(s_target ** 2, dim=1) / (torch.sum(e_noise ** 2, dim=1) + eps))).mean().item()
+    """py/main16.py:764-773: mean SI-SNR (dB) of `s_hat` against `s`, as a Python float"""
+    return _si_snr_db(s, s_hat, eps).mean().item()
 
 
 @torch.no_grad()
@@ -104,7 +184,7 @@ def generate_watermarked_audio(input_file, generator, output_file=None, message_
     si_snr = compute_si_snr(orig, wm)
     power_ratio_db = 10 * np.log10(torch.mean(orig ** 2).item() / max(torch.mean(delta ** 2).item(), 1e-30))
     if output_file:
-        save_audio(output_file, wm)
+        save_audio_float(wm, output_file)                 # :1051-1055 stores the float waveform as is
     return {"watermarked_waveform": wm, "delta_waveform": delta, "original_waveform": orig,
             "metrics": {"watermark_rms": watermark_rms, "si_snr_db": si_snr, "power_ratio_db": power_ratio_db}}
 
@@ -169,13 +249,7 @@ def _si_snr_rows(s, s_hat, eps=1e-8):
     (:1294): the reductions run over dim=1 -- for a 3-D segment that is the size-1 CHANNEL axis, so s - mean == 0 and
     every segment yields 10*log10(0/eps) = -inf.  Kept as is (reference quirk; call compute_si_snr on (1,N) waveforms
     for a meaningful value).  Returns [S] per-segment values."""
-    s = s - s.mean(dim=1, keepdim=True)
-    s_hat = s_hat - s_hat.mean(dim=1, keepdim=True)
-    dot = torch.sum(s * s_hat, dim=1, keepdim=True)
-    alpha = dot / (torch.sum(s ** 2, dim=1, keepdim=True) + eps)
-    s_target = alpha * s
-    e_noise = s_hat - s_target
-    return (10 * torch.log10(torch.sum(s_target ** 2, dim=1) / (torch.sum(e_noise ** 2, dim=1) + eps))).mean(dim=1)
+    return _si_snr_db(s, s_hat, eps).mean(dim=1)
 
 
 @torch.no_grad()

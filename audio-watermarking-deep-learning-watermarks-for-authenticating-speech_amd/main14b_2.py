@@ -388,8 +388,9 @@ class Generator(nn.Module):
     def __init__(self, in_channels=1, base_channels=CHANNELS, hidden_dim=HIDDEN_DIM, message_bits=NUM_BITS,
                  output_channels=OUTPUT_CH, strides=STRIDES):
         super().__init__()
-        if hidden_dim % 32 != 0:
-            raise ValueError("hidden_dim must be a multiple of 32 for the matrix-core gate GEMM")
+        if hidden_dim % 32 != 0 or not 32 <= hidden_dim <= 256:
+            raise ValueError(f"hidden_dim must be a multiple of 32 in [32, 256] (got {hidden_dim}): the recurrence kernels "
+                             "(wm_lstm_seq_fwd/bwd) keep one gate row of W_hh per lane in registers, sized for H <= 256")
         self.message_bits = message_bits
         self.hidden_dim = hidden_dim
         self.strides = list(strides)
@@ -502,12 +503,15 @@ def forward_losses(generator, detector, s, message):
 
 def train_step(generator, detector, optimizer, s, message, grad_sync=None):
     optimizer.zero_grad(set_to_none=not hasattr(optimizer, "flat"))
+    if hasattr(grad_sync, "begin_step"):
+        grad_sync.begin_step()
     with ops.index_check_mode("deferred" if ops._CHECK_INDEX["mode"] == "sync" else ops._CHECK_INDEX["mode"]):
-        total, out = forward_losses(generator, detector, s, message)   # a bad message id raises at the next step (no mid-step sync)
+        total, out = forward_losses(generator, detector, s, message)   # no mid-step sync (it would drain the launch queue)
     total.backward()
     if hasattr(optimizer, "finish_backward"):
         optimizer.finish_backward()
     if grad_sync is not None:
         grad_sync()
+    ops.check_message_ids(wait=True, what="this train_step's batch")    # a bad id raises before the update (step.train_step)
     optimizer.step()
     return out

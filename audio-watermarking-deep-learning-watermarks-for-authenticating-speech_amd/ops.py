@@ -514,7 +514,7 @@ class index_check_mode:
         return False
 
 
-def check_message_ids(wait=True):
+def check_message_ids(wait=True, what="an earlier Generator call"):
     """raise IndexError if a deferred message-id check has failed (wait=False: only look at flags that have already landed)"""
     keep = []
     for ev, host, nrows in _CHECK_INDEX["pending"]:
@@ -524,7 +524,7 @@ def check_message_ids(wait=True):
         ev.synchronize()
         if int(host[0]) != 0:
             _CHECK_INDEX["pending"] = []
-            raise IndexError(f"message id out of range for an embedding table of {nrows} rows (detected by a deferred check)")
+            raise IndexError(f"message id out of range for an embedding table of {nrows} rows (deferred check of {what})")
     _CHECK_INDEX["pending"] = keep
 
 

@@ -33,8 +33,20 @@ T = 16000
 PEAK_FP32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0      # MI355X_MICROARCH.md: dense bf16 MFMA peak (no sparsity)
 PEAK_HBM_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E spec (6.3 TB/s achievable)
-PMC_MAIN16 = "r02_pmc_fetch_write_b256.json"          # profiles/: per-kernel HBM bytes, made by profiles/summarize_pmc.py
-PMC_MAIN14B2 = "r02_pmc_fetch_write_main14b2_b128.json"
+PMC_MAIN16 = "r03_pmc_fetch_write_b256.json"          # profiles/: per-kernel HBM bytes, made by profiles/summarize_pmc.py
+PMC_MAIN14B2 = "r03_pmc_fetch_write_main14b2_b128.json"
+
+
+def kernel_source_sha():
+    """SHA-256 over the HIP sources the library is built from -- profiles/summarize_pmc.py stores the same digest in the PMC
+    summary, so a `traffic` figure taken on an older build of the kernels is recognised and dropped instead of going stale"""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "audio-watermarking-deep-learning-watermarks-for-authenticating-speech_amd", "csrc", "*.h*"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def synthetic_batch(batch, rank, dev):
@@ -76,22 +88,76 @@ class LaunchTimer:
 
 
 def pmc_traffic(fname, prefixes):
-    """mean HBM bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
-    in separate runs, gfx950 FETCH x2 correction; profiles/summarize_pmc.py) -- None when the file is absent"""
+    """(mean HBM bytes per launch of the named kernel, note) from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE in separate runs, gfx950 FETCH x2 correction; profiles/summarize_pmc.py).  (None, why) when the file is absent,
+    has no such kernel, or was taken on different kernel sources than the ones this run was built from."""
     try:
-        pm = json.load(open(os.path.join(ROOT, "profiles", fname)))["kernels"]
-        ks = [v["hbm_bytes_per_launch_corrected"] for k, v in pm.items() if k.startswith(tuple(prefixes))]
-        return sum(ks) / len(ks) if ks else None
+        doc = json.load(open(os.path.join(ROOT, "profiles", fname)))
     except Exception:
-        return None
+        return None, f"profiles/{fname} not found"
+    if doc.get("kernel_source_sha") != kernel_source_sha():
+        return None, f"profiles/{fname} was taken on other kernel sources ({doc.get('kernel_source_sha')}): dropped, not reported stale"
+    ks = [v["hbm_bytes_per_launch_corrected"] for k, v in doc["kernels"].items() if k.startswith(tuple(prefixes))]
+    if not ks:
+        return None, f"no kernel named {prefixes} in profiles/{fname}"
+    return sum(ks) / len(ks), f"profiles/{fname}, mean over kernels {list(prefixes)}"
 
 
-def cpu_baseline_main16(sample_batch=2, steps=1):
+def host_cpus():
+    """(CPUs this process may use, CPU model): the scheduler affinity mask capped by the cgroup quota -- a one-GPU box hands a
+    share of the host's cores to the job, and a thread pool sized by the machine's core count only oversubscribes it"""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(float(quota) / float(period) + 0.5)))
+    except Exception:
+        pass
+    try:
+        import psutil
+        n = max(1, min(n, psutil.cpu_count(logical=False) or n))
+    except Exception:
+        pass
+    model = "unknown CPU"
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                model = ln.split(":", 1)[1].strip()
+                break
+    except Exception:
+        pass
+    return n, model
+
+
+def _cpu_leg(one_small, one_full, sample_batch, budget_s):
+    """BASELINE.md section 3's plan within a time budget: for n in {8 threads, every core the job may use}: one warm-up step (on a
+    2-clip batch: thread pool, allocator, oneDNN primitives), then B=`sample_batch` steps until the budget share is used (>= 1)."""
+    avail, model = host_cpus()
+    runs = []
+    counts = sorted({min(8, avail), avail})
+    prev = torch.get_num_threads()
+    try:
+        for n in counts:
+            torch.set_num_threads(n)
+            one_small()
+            t0, k = time.perf_counter(), 0
+            while k == 0 or (time.perf_counter() - t0 < budget_s / len(counts) and k < 5):
+                one_full()
+                k += 1
+            dt = (time.perf_counter() - t0) / k
+            runs.append({"threads": n, "clips_per_s": round(sample_batch / dt, 3), "s_per_step": round(dt, 2), "timed_steps": k})
+    finally:
+        torch.set_num_threads(prev)
+    best = max(runs, key=lambda r: r["clips_per_s"])
+    return runs, best, avail, model
+
+
+def cpu_baseline_main16(sample_batch=16, budget_s=24.0):
     """The oracle (CPU restatement, kind "port") timed on this box's host cores on a bounded sample of the same workload:
-    B=2 train steps (fwd + bwd + Adam), 1 warm-up + `steps` timed (about 15-20 s of CPU work in all)."""
+    train steps (fwd + bwd + Adam) at B=16 -- the reference's own BATCH_SIZE (py/main16.py:32) -- with 8 threads and with every core
+    the job may use; `value` is the faster of the two, both are listed under `runs`."""
     from oracle import recipes as R
     from oracle import wm_oracle as O
-    nthreads = torch.get_num_threads()
     gsd, dsd = R.reference_layout_init()
     params = []
     for sd in (gsd, dsd):
@@ -103,45 +169,40 @@ def cpu_baseline_main16(sample_batch=2, steps=1):
     s = O.synthetic_clips(sample_batch, seed=1234)
     msg = O.synthetic_messages(sample_batch, seed=4321)
 
-    def one():
+    def one(b):
         opt.zero_grad()
-        total, _ = O.step_losses(gsd, dsd, s, msg, training=True, g_stats={}, d_stats={})
+        total, _ = O.step_losses(gsd, dsd, s[:b], msg[:b], training=True, g_stats={}, d_stats={})
         total.backward()
         opt.step()
-    one()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        one()
-    dt = (time.perf_counter() - t0) / steps
-    return {"value": sample_batch / dt, "unit": "clips/s", "cores": nthreads, "kind": "port",
-            "sample": f"oracle/wm_oracle.py train step (fwd+bwd+Adam), B={sample_batch}, 1 warm-up + {steps} timed steps, "
-                      f"{dt:.2f} s/step, torch CPU fp32 with {nthreads} threads"}
+    runs, best, avail, model = _cpu_leg(lambda: one(2), lambda: one(sample_batch), sample_batch, budget_s)
+    return {"value": best["clips_per_s"], "unit": "clips/s", "cores": best["threads"], "kind": "port", "runs": runs,
+            "cpu_model": model, "cpus_available_to_job": avail,
+            "sample": f"oracle/wm_oracle.py train step (fwd+bwd+Adam), B={sample_batch}, torch CPU fp32 on {model}; per thread count one "
+                      f"2-clip warm-up step then B={sample_batch} steps within {budget_s:.0f} s in all: "
+                      + "; ".join(f"{r['threads']} threads {r['s_per_step']} s/step x {r['timed_steps']}" for r in runs)}
 
 
-def cpu_baseline_main14b2(G, D, sample_batch=2, steps=1):
+def cpu_baseline_main14b2(G, D, sample_batch=16, budget_s=24.0):
     """same for configs[4]: oracle/wm_oracle_14b2.py step (hidden 256) on the host cores, weights = the modules' own"""
     from oracle import wm_oracle as O
     from oracle import wm_oracle_14b2 as O2
-    nthreads = torch.get_num_threads()
     gsd = {k: v.detach().cpu().clone().requires_grad_(v.is_floating_point()) for k, v in G.state_dict().items()}
     dsd = {k: v.detach().cpu().clone().requires_grad_(v.is_floating_point()) for k, v in D.state_dict().items()}
     opt = torch.optim.Adam([v for v in list(gsd.values()) + list(dsd.values()) if v.requires_grad], lr=1e-3)
     s = O.synthetic_clips(sample_batch, seed=1234)
     msg = O.synthetic_messages(sample_batch, seed=4321)
 
-    def one():
+    def one(b):
         opt.zero_grad()
-        total, _ = O2.step_losses(gsd, dsd, s, msg)
+        total, _ = O2.step_losses(gsd, dsd, s[:b], msg[:b])
         total.backward()
         opt.step()
-    one()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        one()
-    dt = (time.perf_counter() - t0) / steps
-    return {"value": sample_batch / dt, "unit": "clips/s", "cores": nthreads, "kind": "port",
-            "sample": f"oracle/wm_oracle_14b2.py train step (hidden 256, fwd+bwd+Adam), B={sample_batch}, 1 warm-up + {steps} timed "
-                      f"steps, {dt:.2f} s/step, torch CPU fp32 with {nthreads} threads"}
+    runs, best, avail, model = _cpu_leg(lambda: one(2), lambda: one(sample_batch), sample_batch, budget_s)
+    return {"value": best["clips_per_s"], "unit": "clips/s", "cores": best["threads"], "kind": "port", "runs": runs,
+            "cpu_model": model, "cpus_available_to_job": avail,
+            "sample": f"oracle/wm_oracle_14b2.py train step (hidden 256, fwd+bwd+Adam), B={sample_batch}, torch CPU fp32 on {model}; per "
+                      f"thread count one 2-clip warm-up step then B={sample_batch} steps within {budget_s:.0f} s in all: "
+                      + "; ".join(f"{r['threads']} threads {r['s_per_step']} s/step x {r['timed_steps']}" for r in runs)}
 
 
 def build_workload(model, mode, batch, rank, world, dev, torch_adam=False, force_sync=False):
@@ -180,30 +241,82 @@ def build_workload(model, mode, batch, rank, world, dev, torch_adam=False, force
             return step_fn(G, D, opt, s, msg, grad_sync=sync)
 
     bf_mode = _ops.conv_bf16x6()
+    return G, D, step, kernel_timers(awm_amd.lib, model, mode, bf_mode, batch), bf_mode
+
+
+BF16X6_PEAK = PEAK_BF16_MFMA_TFLOPS / 6.0
+BF16X6_NOTE = "bf16 dense MFMA peak 2500 TFLOP/s / 6 bf16 piece products per fp32-grade product"
+FP32_NOTE = "fp32 MFMA dense peak (v_mfma_f32_32x32x2_f32)"
+
+
+def kernel_timers(lib, model, mode, bf_mode, batch):
+    """HIP-event timers on the C-ABI entry points whose kernels carry the workload, the DOMINANT one first (share of the step's
+    kernel time in the committed rocprofv3 summary under profiles/).  Each entry names the kernel it brackets, its algorithmic
+    FLOPs / bytes per launch, the peak it is priced against and where its PMC traffic figure comes from -- the roofline object of
+    the JSON line is built from the entry itself, never from strings kept elsewhere."""
+    from awm_amd import ops as _ops
+    pmc16 = PMC_MAIN16 if batch == 256 else None
     if model == "main14b_2":
-        # dominant kernel: gconv2_kernel<2,2,2> -- the 128 x 128-tile build of the generic implicit-GEMM convolution
-        # (wm_gconv with > 64 output rows, > 64 output positions, 16-byte-aligned weight rows): forward convolutions,
-        # transposed convolutions and every data gradient of the wide layers.
-        # args: x wp bias vec res y NB Cin Lin K S P Mtot Nout st shp Cout Lout act stream
-        timer = LaunchTimer(awm_amd.lib, "wm_gconv", lambda a: a[12] > 64 and a[13] > 64 and a[12] % 4 == 0,
-                            lambda a: (2.0 * a[6] * a[7] * a[9] * a[12] * a[13], 4.0 * a[6] * (a[7] * a[8] + a[16] * a[17])))
-    elif bf_mode and mode == "fwd" and _ops._CONV["one_launch_eval"]:
-        # inference: the ResBlock is ONE launch (two 64->64 k3 convolutions back to back; x in, out out)
+        # wm_gconv args: x wp bias vec res y NB Cin Lin K S P Mtot Nout st shp Cout Lout act stream; > 64 output rows and
+        # positions with 16-byte-aligned weight rows = the 128 x 128-tile build
+        return [dict(timer=LaunchTimer(lib, "wm_gconv", lambda a: a[12] > 64 and a[13] > 64 and a[12] % 4 == 0,
+                                       lambda a: (2.0 * a[6] * a[7] * a[9] * a[12] * a[13], 4.0 * a[6] * (a[7] * a[8] + a[16] * a[17]))),
+                     kernel="gconv2_kernel<2,2,2> (wm_gconv, 128 x 128 output tiles: implicit-GEMM Conv1d / ConvTranspose1d / data "
+                            "gradients of the wide main14b_2 layers on the fp32 matrix cores; achieved = sum of algorithmic FLOPs / "
+                            "sum of launch times)",
+                     peak=PEAK_FP32_MFMA_TFLOPS, note=FP32_NOTE, pmc=PMC_MAIN14B2 if batch == 128 else None,
+                     pmc_prefixes=("gconv2_kernel<2, 2, 2",))]
+    if not bf_mode:
+        return [dict(timer=LaunchTimer(lib, "wm_conv64", lambda a: a[14] == 3 and a[16] == 0,
+                                       lambda a: (2.0 * 64 * 64 * 3 * a[13] * a[12], 2.0 * 64 * a[13] * 4 * a[12])),
+                     kernel="conv64_kernel<KW=3> forward (wm_conv64: native fp32 MFMA; BN+ReLU fused on load, BN sums in epilogue)",
+                     peak=PEAK_FP32_MFMA_TFLOPS, note=FP32_NOTE, pmc=pmc16, pmc_prefixes=("conv64_kernel<3, 256",))]
+    fwd = dict(timer=LaunchTimer(lib, "wm_conv64_bf", lambda a: a[15] == 0,
+                                 lambda a: (2.0 * 64 * 64 * 3 * a[13] * a[12], 2.0 * 64 * a[13] * 4 * a[12])),
+               kernel="conv64bf3_kernel forward (wm_conv64_bf, epilogue = bias: Conv1d(64,64,3) as bf16x6 split products on the bf16 matrix "
+                      "cores, fp32 accumulate, fp32-grade error; BN+ReLU fused on load, BN sums in the epilogue)",
+               peak=BF16X6_PEAK, note=BF16X6_NOTE, pmc=pmc16, pmc_prefixes=("conv64bf3_kernel<0, 0", "conv64bf3_kernel<1, 0"))
+    if mode == "fwd":
+        if not _ops._CONV["one_launch_eval"]:
+            return [fwd]
         # args: x w1pb w2pb b1 sc1 sh1 b2 sc2 sh2 y B T stream
-        timer = LaunchTimer(awm_amd.lib, "wm_resblock_eval_bf", lambda a: True,
-                            lambda a: (2.0 * 2.0 * 64 * 64 * 3 * a[11] * a[10], 2.0 * 64 * a[11] * 4 * a[10]))
-    elif bf_mode:
-        # dominant kernel: the 64->64 k3 forward convolution of the ResBlocks (epi = bias): wm_conv64_bf (bf16x6 split build)
-        timer = LaunchTimer(awm_amd.lib, "wm_conv64_bf", lambda a: a[15] == 0,
-                            lambda a: (2.0 * 64 * 64 * 3 * a[13] * a[12], 2.0 * 64 * a[13] * 4 * a[12]))
-    else:
-        timer = LaunchTimer(awm_amd.lib, "wm_conv64", lambda a: a[14] == 3 and a[16] == 0,
-                            lambda a: (2.0 * 64 * 64 * 3 * a[13] * a[12], 2.0 * 64 * a[13] * 4 * a[12]))
-    return G, D, step, timer, bf_mode
+        return [dict(timer=LaunchTimer(lib, "wm_resblock_eval_bf", lambda a: True,
+                                       lambda a: (2.0 * 2.0 * 64 * 64 * 3 * a[11] * a[10], 2.0 * 64 * a[11] * 4 * a[10])),
+                     kernel="resblock_eval_kernel (wm_resblock_eval_bf: the inference ResBlock in one launch -- conv1 + BN1 + ReLU, the "
+                            "intermediate kept in LDS as bf16x3 pieces, conv2 + BN2 + residual + ReLU; bf16x6 split products)",
+                     peak=BF16X6_PEAK, note=BF16X6_NOTE, pmc=None, pmc_prefixes=())]
+    if not _ops._CONV["fused_bwd"]:
+        return [fwd]
+    # ResBlock backward: data gradient + weight gradient of one Conv1d(64,64,3) in ONE launch = two GEMMs of 2*64*64*3*T*B flops.
+    # args: dz y A Bc C wpb xin sc sh e1 ea eb dx stats wpart dw db B T pro epi accumulate stream; epi 1 = conv2 pair (reads dz2 y2
+    # y1, writes dz1: 4 frames), epi 2 = conv1 pair (reads dz1 y1 x dz2, writes dx: 5 frames)
+    dw = dict(timer=LaunchTimer(lib, "wm_dwgrad64_bf", lambda a: True,
+                                lambda a: (2.0 * 2.0 * 64 * 64 * 3 * a[18] * a[17], (4.0 if a[20] == 1 else 5.0) * 64 * a[18] * 4 * a[17])),
+              kernel="dwgrad64bf_kernel<1,1> + <2,0> (wm_dwgrad64_bf: data gradient AND weight gradient of a ResBlock Conv1d(64,64,3) in one "
+                     "launch -- BN-backward rebuilt on load, ReLU mask / BN sums / residual add in the epilogue; bf16x6 split products, "
+                     "fp32 accumulate; 30 % of the step's kernel time)",
+              peak=BF16X6_PEAK, note=BF16X6_NOTE, pmc=pmc16, pmc_prefixes=("dwgrad64bf_kernel<",))
+    return [dw, fwd]
+
+
+def roofline_of(entry):
+    """the `roofline` object of one timed kernel family (None when it was never launched in the timed region)"""
+    n, k_ms, flops, byts = entry["timer"].totals()
+    if not n:
+        return None
+    ach = flops / (k_ms * 1e-3) / 1e12
+    traffic, tnote = pmc_traffic(entry["pmc"], entry["pmc_prefixes"]) if entry["pmc"] else (None, "no PMC pass exists for this batch size")
+    return {"bound": "mfma", "achieved": round(ach, 2), "peak": round(entry["peak"], 1), "unit": "TFLOP/s",
+            "frac": round(ach / entry["peak"], 4), "traffic": traffic, "traffic_source": tnote, "peak_note": entry["note"],
+            "achieved_over_fp32_mfma_peak_157TF": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "kernel": entry["kernel"],
+            "avg_launch_ms": round(k_ms / n, 4), "launches_timed": n,
+            "algorithmic_flops_per_launch": flops / n, "algorithmic_bytes_per_launch": byts / n,
+            "hbm_achieved_GBs": round(byts / (k_ms * 1e-3) / 1e9, 1),
+            "hbm_frac_of_8TBs": round(byts / (k_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
 
 
 def run_workload(model, mode, batch, steps, warmup, rank, world, dev, dist, torch_adam=False, force_sync=False):
-    G, D, step, timer, bf_mode = build_workload(model, mode, batch, rank, world, dev, torch_adam, force_sync)
+    G, D, step, timers, bf_mode = build_workload(model, mode, batch, rank, world, dev, torch_adam, force_sync)
     for _ in range(warmup):
         step()
 
@@ -214,14 +327,16 @@ def run_workload(model, mode, batch, steps, warmup, rank, world, dev, dist, torc
         torch.cuda.synchronize()
 
     fence()
-    timer.on = True
+    for e in timers:
+        e["timer"].on = True
     t0 = time.perf_counter()
     for _ in range(steps):
         out = step()
     fence()
     dt = time.perf_counter() - t0
-    timer.on = False
-    timer.restore()
+    for e in timers:
+        e["timer"].on = False
+        e["timer"].restore()
     if world > 1:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -229,38 +344,9 @@ def run_workload(model, mode, batch, steps, warmup, rank, world, dev, dist, torc
     tot = out["total"] if mode == "train" else out["delta_rms"].mean()
     total_loss = float(tot.detach()) if torch.is_tensor(tot) else float(tot)
     assert total_loss == total_loss, "NaN"
-    n, k_ms, flops, byts = timer.totals()
-    roofline = None
-    if n:
-        ach = flops / (k_ms * 1e-3) / 1e12
-        if model == "main14b_2":
-            peak, note = PEAK_FP32_MFMA_TFLOPS, "fp32 MFMA dense peak (v_mfma_f32_32x32x2_f32)"
-            kernel = ("gconv2_kernel<2,2,2> (wm_gconv, 128 x 128 output tiles: implicit-GEMM Conv1d / ConvTranspose1d / data gradients of "
-                      "the wide main14b_2 layers on the fp32 matrix cores; achieved = sum of algorithmic FLOPs / sum of launch times)")
-            traffic = pmc_traffic(PMC_MAIN14B2, ("gconv2_kernel<2, 2, 2",)) if batch == 128 else None
-        else:
-            # bf16x6 mode runs on the bf16 matrix pipe (dense peak 2500 TFLOP/s) and spends six piece products per fp32-grade
-            # product: its ceiling in ALGORITHMIC flops is 2500/6 = 416.7 TFLOP/s.  Native mode: the fp32 MFMA peak.
-            peak = (PEAK_BF16_MFMA_TFLOPS / 6.0) if bf_mode else PEAK_FP32_MFMA_TFLOPS
-            note = ("bf16 dense MFMA peak 2500 TFLOP/s / 6 bf16 piece products per fp32-grade product" if bf_mode
-                    else "fp32 MFMA dense peak (v_mfma_f32_32x32x2_f32)")
-            kernel = ("conv64bf3_kernel forward (wm_conv64_bf: Conv1d(64,64,3)+bias as bf16x6 split products on the bf16 matrix cores, "
-                      "fp32 accumulate, fp32-grade error; BN+ReLU fused on load, BN sums in epilogue)") if bf_mode else \
-                "conv64_kernel<KW=3> forward (wm_conv64: native fp32 MFMA; BN+ReLU fused on load, BN sums in epilogue)"
-            if timer.name == "wm_resblock_eval_bf":
-                kernel = ("resblock_eval_kernel (wm_resblock_eval_bf: the inference ResBlock in one launch -- conv1 + BN1 + ReLU, the "
-                          "intermediate kept in LDS as bf16x3 pieces, conv2 + BN2 + residual + ReLU; bf16x6 split products)")
-            pref = ("conv64bf3_kernel<0, 0", "conv64bf3_kernel<1, 0") if bf_mode else ("conv64_kernel<3, 256",)
-            traffic = pmc_traffic(PMC_MAIN16, pref) if batch == 256 else None
-        roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-                    "frac": round(ach / peak, 4), "traffic": traffic, "peak_note": note,
-                    "achieved_over_fp32_mfma_peak_157TF": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "kernel": kernel,
-                    "avg_launch_ms": round(k_ms / n, 4), "launches_timed": n,
-                    "algorithmic_flops_per_launch": flops / n, "algorithmic_bytes_per_launch": byts / n,
-                    "hbm_achieved_GBs": round(byts / (k_ms * 1e-3) / 1e9, 1),
-                    "hbm_frac_of_8TBs": round(byts / (k_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
-    res = {"ms_per_step": 1e3 * dt / steps, "value": batch * world * steps / dt, "loss": total_loss, "roofline": roofline,
-           "bf_mode": bf_mode, "modules": (G, D)}
+    roofs = [r for r in (roofline_of(e) for e in timers) if r is not None]
+    res = {"ms_per_step": 1e3 * dt / steps, "value": batch * world * steps / dt, "loss": total_loss,
+           "roofline": roofs[0] if roofs else None, "roofline_other_kernels": roofs[1:], "bf_mode": bf_mode, "modules": (G, D)}
     return res
 
 
@@ -352,6 +438,8 @@ def main():
                            if (args.model == "main16" and bf_mode) else "native fp32 MFMA",
                            "parallelism": f"dp{world}" if world > 1 else "single"},
                 "loss": round(r["loss"], 6), "roofline": r["roofline"]}
+        if r["roofline_other_kernels"]:
+            line["roofline_other_kernels"] = r["roofline_other_kernels"]
         if world == 1 and not args.no_cpu_baseline and args.mode == "train":
             line["cpu_baseline"] = cpu_baseline_main16() if args.model == "main16" else cpu_baseline_main14b2(*r["modules"])
         default_run = (args.model == "main16" and args.mode == "train" and args.batch == 256 and world == 1 and not args.no_extra

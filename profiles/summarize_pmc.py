@@ -39,7 +39,10 @@ def main():
             "correction), WRITE exact.  bytes_per_step = sum over kernels of dispatches x mean bytes / steps run (3 = 1 warm-up + 2).")
     steps = 3.0
     total = sum(v["dispatches"] * v["hbm_bytes_per_launch_corrected"] for v in kernels.values()) / steps
-    json.dump({"note": note, "hbm_bytes_per_step": int(total), "kernels": kernels}, open(out, "w"), indent=1)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import kernel_source_sha          # digest of csrc/*.hip + *.hpp: bench.py drops a summary taken on other sources
+    json.dump({"note": note, "kernel_source_sha": kernel_source_sha(), "hbm_bytes_per_step": int(total), "kernels": kernels},
+              open(out, "w"), indent=1)
     print(f"{len(kernels)} kernels -> {out}")
 
 

@@ -82,18 +82,64 @@ def test_two_ranks_share_one_gpu_hip_path(tmp_path):
 
 
 @pytest.mark.timeout(900)
-def test_bench_launches_its_own_ranks(tmp_path):
+def test_two_ranks_share_one_gpu_main14b2(tmp_path):
+    """BASELINE configs[4]'s exchange (py/main14b_2.py:300-352 step, 24 893 874 parameters = 99.6 MB bucket): two ranks with the
+    real HIP modules; replicas bit-identical after two exchanged steps, rank-averaged gradient = big-batch gradient."""
+    import awm_amd
+    from awm_amd import main14b_2 as M14
+    dev = torch.device("cuda:0")
+    n_total, T = 4, 6400
+    _spawn_ranks([os.path.join(ROOT, "tests", "dist_rehearsal.py"), str(tmp_path), str(n_total), str(T), "main14b_2"], world=2)
+    r0, r1 = torch.load(tmp_path / "rank0.pt"), torch.load(tmp_path / "rank1.pt")
+    assert r0["bucket_bytes"] == 4 * 24893874
+    assert torch.equal(r0["flat"], r1["flat"]), float((r0["flat"] - r1["flat"]).abs().max())
+    assert all(abs(a) < 1e6 for a in r0["losses"] + r1["losses"])
+    torch.manual_seed(42)
+    G, D = M14.Generator(hidden_dim=256).to(dev).train(), M14.Detector().to(dev).train()
+    opt = awm_amd.FlatAdam([G, D], lr=1e-3)
+    opt.zero_grad()
+    s = O.synthetic_clips(n_total, seed=41, T=T).to(dev)
+    msg = O.synthetic_messages(n_total, seed=42).to(dev)
+    M14.forward_losses(G, D, s, msg)[0].backward()
+    opt.finish_backward()
+    big, avg = opt.grad.cpu(), torch.load(tmp_path / "avg_grad.pt")
+    for (off, k), p in zip(opt._spans, opt.params):
+        a, b = avg[off:off + k], big[off:off + k]
+        scale = float(b.abs().max())
+        if scale == 0.0:
+            assert float(a.abs().max()) == 0.0
+            continue
+        assert float((a - b).abs().max()) <= 3e-3 * scale + 1e-7, (off, k, float((a - b).abs().max()), scale)
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("model", ["main16", "main14b_2"])
+def test_gradsync_production_path_on_one_rank_rccl(tmp_path, model):
+    """distributed.GradSync's RCCL path (hook-launched async all-reduce of the Detector span on a side stream, join in
+    __call__) on a one-rank nccl communicator in a fresh child process: exchanged gradient == plain gradient bit for bit,
+    stale-state hazards (a backward without an exchange; a second backward) handled.  tests/dist_rehearsal.py force_sync"""
+    T = 2048 if model == "main16" else 3200
+    _spawn_ranks([os.path.join(ROOT, "tests", "dist_rehearsal.py"), str(tmp_path), "2", str(T), model, "force_sync"], world=1)
+    r = torch.load(tmp_path / "force_sync.pt")
+    assert r["same"], r["max_diff"]
+    assert r["refused"] and all(abs(a) < 1e6 for a in r["losses"])
+    assert r["bucket_bytes"] == 4 * (4383314 if model == "main16" else 24893874)
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("model,batch", [("main16", 8), ("main14b_2", 4)])
+def test_bench_launches_its_own_ranks(tmp_path, model, batch):
     """`python bench.py --gpus 2` (no torchrun in front, as the driver's bare form) starts two ranks itself; both share
     the one GPU over gloo here.  One JSON line, n_gpus = 2, weak scaling: global batch = 2 x per-GPU batch."""
     env = dict(os.environ, WM_BENCH_SHARE_GPU="1", WM_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.pop("RANK", None); env.pop("WORLD_SIZE", None); env.pop("LOCAL_RANK", None)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-                        "--batch", "8", "--no-cpu-baseline"], env=env, cwd=ROOT, capture_output=True, text=True, timeout=800)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--model", model,
+                        "--batch", str(batch), "--no-cpu-baseline"], env=env, cwd=ROOT, capture_output=True, text=True, timeout=800)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout
     line = json.loads(lines[0])
-    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["config"]["global_batch"] == 16
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["config"]["global_batch"] == 2 * batch
     assert line["value"] > 0 and line["loss"] == line["loss"]
 
 

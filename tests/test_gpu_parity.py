@@ -659,6 +659,152 @@ def test_all_grads_vs_oracle(awm, dev):
         ops.set_conv_bf16x6(prev)
 
 
+def _dft_logmel(x, n_fft=1024, hop=256):
+    """log-mel spectrogram of MultiScaleMelLoss's configuration out of matmuls only (framing by unfold, real DFT as two dense
+    products, the oracle's HTK filterbank): one definition that runs on the CPU in fp64 and on the GPU in fp32 under torch's own
+    autograd -- the smooth surrogate's building block.  Test infrastructure, not the product."""
+    dt, dv = x.dtype, x.device
+    pad = n_fft // 2
+    xp = F.pad(x, (pad, pad), mode="reflect").squeeze(1)
+    fr = xp.unfold(1, n_fft, hop)                                            # [B, F, n_fft]
+    n = torch.arange(n_fft, dtype=torch.float64)
+    win = (0.5 - 0.5 * torch.cos(2 * np.pi * n / n_fft))
+    k = torch.arange(n_fft // 2 + 1, dtype=torch.float64)
+    ang = 2 * np.pi * torch.outer(n, k) / n_fft
+    cr, ci = (win[:, None] * torch.cos(ang)).to(dt).to(dv), (win[:, None] * torch.sin(ang)).to(dt).to(dv)
+    power = (fr @ cr) ** 2 + (fr @ ci) ** 2                                  # [B, F, 513]
+    fb = O.mel_filterbank().to(dt).to(dv)                                    # [513, 64]
+    return torch.log(power @ fb + 1e-5)
+
+
+def test_all_grads_smooth_surrogate(awm, dev):
+    """test_all_grads_vs_oracle's 5e-3 floor is the LOSS, not a kernel: with the one term that is discontinuous in round-off
+    (F.l1_loss of log-mel differences of size ~1e-6: its gradient is a sum of signs) replaced by a smooth surrogate of the same
+    magnitude -- K x mean squared log-mel difference -- every parameter gradient of the SAME step (Generator, post-processing,
+    Detector, loud / loc / bce / l1 / hf terms through the HIP kernels) sits within max(2 x e_cpu, 3e-4 | 2e-3 biases) of the
+    fp64 run, in both convolution arithmetic modes."""
+    from awm_amd import ops
+    from awm_amd.step import LOSS_WEIGHTS as W
+    B, T = 3, 4000
+    gsd, dsd = states()
+    msg = O.synthetic_messages(B, seed=71)
+    for seed in range(70, 170):      # keep every sample away from clamp_peak's derivative discontinuity
+        s = O.synthetic_clips(B, seed=seed, T=T)
+        with torch.no_grad():
+            f = O.fir_lowpass(O.generator_forward(gsd, s, msg, training=True))
+        if float((f.abs() - 0.02).abs().min()) >= 1e-5 * float(f.abs().max()):
+            break
+
+    def cpu_run(dtype):
+        g = {k: (v.to(dtype) if v.is_floating_point() else v).clone().requires_grad_(v.dtype.is_floating_point and "running" not in k) for k, v in gsd.items()}
+        d = {k: (v.to(dtype) if v.is_floating_point() else v).clone().requires_grad_(v.dtype.is_floating_point and "running" not in k) for k, v in dsd.items()}
+        _, o = O.step_losses(g, d, s.to(dtype), msg, training=True, g_stats={}, d_stats={})
+        msq = ((_dft_logmel(s.to(dtype)) - _dft_logmel(o["s_w"])) ** 2).mean()
+        return g, d, o, msq
+    g2, d2, o2, msq2 = cpu_run(torch.float64)
+    K = float(o2["mel"].detach() / msq2.detach())                           # surrogate term as large as the term it replaces
+
+    def total_of(o, msq):
+        return W["l1"] * o["l1"] + W["mel"] * K * msq + W["loud"] * o["loud"] + W["loc"] * o["loc"] + W["bce"] * o["bce"] + W["hf"] * o["hf"]
+    total_of(o2, msq2).backward()
+    g3, d3, o3, msq3 = cpu_run(torch.float32)
+    total_of(o3, msq3).backward()
+    prev = ops.conv_bf16x6()
+    try:
+        for mode in (True, False):
+            ops.set_conv_bf16x6(mode)
+            G, D, _, _ = make_models(awm, dev, gsd, dsd)
+            G.train(); D.train()
+            _, out = awm.forward_losses(G, D, s.to(dev), msg.to(dev))
+            msq = ((_dft_logmel(s.to(dev)) - _dft_logmel(out["s_w"])) ** 2).mean()
+            check(msq.reshape(1), msq2.reshape(1), 1e-3, "surrogate value")
+            total_of(out, msq).backward()
+            table = []
+            for name, mod, ref, c32 in (("G", G, g2, g3), ("D", D, d2, d3)):
+                for k, p in mod.named_parameters():
+                    if k.endswith("block.0.bias") or k.endswith("block.3.bias"):
+                        continue          # exactly-zero true gradient, fp32 noise on both sides
+                    e, e_cpu = rel_err(p.grad, ref[k].grad), rel_err(c32[k].grad, ref[k].grad)
+                    floor = GRAD_FLOOR
+                    if k.endswith(".bias"):
+                        kw = k[:-4] + "weight"
+                        scale = max(float(ref[k].grad.abs().max()), float(ref[kw].grad.abs().max()))
+                        e = float((p.grad.double().cpu() - ref[k].grad).abs().max()) / scale
+                        floor = GRAD_FLOOR_BIAS
+                    table.append((e / max(2.0 * e_cpu, floor), f"{name}.{k}", e, e_cpu))
+            bad = [t for t in table if t[0] > 1.0]
+            assert not bad, "smooth-loss gradients outside max(2 x e_cpu, %g) (ratio, name, hip-vs-fp64, cpu32-vs-fp64), bf16x6=%s: %s" % (
+                GRAD_FLOOR, mode, sorted(bad, reverse=True)[:8])
+            print("smooth surrogate: worst ratio to the bar", max(t[0] for t in table), "bf16x6 =", mode)
+    finally:
+        ops.set_conv_bf16x6(prev)
+
+
+@pytest.mark.parametrize("B,T", [(3, 4000), (2, 16000)])
+def test_validation_recipe_vs_oracle(awm, dev, B, T):
+    """validate_one_epoch's batch body (py/main16.py:312-347): eval-mode BatchNorm (running statistics, none updated) + all six
+    loss terms under no_grad, the HIP path against the oracle's step_losses(training=False): the 8 scalars element-wise at
+    rtol 1e-4, delta and logits element-wise."""
+    G, D, gsd, dsd = make_models(awm, dev)
+    G.eval(); D.eval()
+    s = O.synthetic_clips(B, seed=611, T=T)
+    msg = O.synthetic_messages(B, seed=612)
+    before = {k: v.clone() for k, v in list(G.state_dict().items()) + list(D.state_dict().items())}
+    with torch.no_grad():
+        _, ref = O.step_losses(gsd, dsd, s, msg, training=False)
+        total, out = awm.forward_losses(G, D, s.to(dev), msg.to(dev))
+    assert not total.requires_grad
+    for k in ("l1", "mel", "loud", "loc", "bce", "hf", "raw_total", "total"):
+        a, r = float(out[k]), float(ref[k])
+        assert abs(a - r) <= 1e-4 * abs(r), f"validation {k}: {a} vs {r}"
+    check_elementwise(out["delta_raw"], ref["delta_raw"], "validation delta_raw")
+    check_elementwise(out["delta"], ref["delta"], "validation delta", atol_of_max=2e-6)
+    check_elementwise(out["logits"], ref["logits"], "validation logits", atol_of_max=2e-6)
+    after = dict(list(G.state_dict().items()) + list(D.state_dict().items()))
+    for k, v in before.items():
+        assert torch.equal(v, after[k]), f"eval-mode pass changed {k}"
+
+
+def test_bad_message_id_never_reaches_the_update(awm, dev):
+    """train_step keeps the message-id check off the launch queue (deferred flag) but reads it before optimizer.step():
+    nn.Embedding's IndexError (py/main16.py:158) is raised for THIS batch and the weights are untouched"""
+    from awm_amd import ops
+    G, D, _, _ = make_models(awm, dev)
+    G.train(); D.train()
+    opt = awm.FlatAdam([G, D], lr=1e-3)
+    s = O.synthetic_clips(2, seed=5, T=1024).to(dev)
+    before = opt.flat.clone()
+    with pytest.raises(IndexError, match="this train_step"):
+        awm.train_step(G, D, opt, s, torch.tensor([3, 65536], device=dev))
+    assert torch.equal(opt.flat, before) and opt.t == 0
+    ops.check_message_ids()                                                  # nothing left pending
+    awm.train_step(G, D, opt, s, torch.tensor([3, 65535], device=dev))
+    assert opt.t == 1 and not torch.equal(opt.flat, before)
+
+
+def test_resumable_checkpoint_leaves_torch_adam_on_the_gpu(awm, dev, tmp_path):
+    """py/main14d.py:540-558 with torch.optim.Adam (the reference's optimizer): save_resumable copies the state, it must not
+    move the running optimizer's moments to the CPU (Optimizer.state_dict() hands out the live per-parameter dicts)"""
+    from awm_amd import checkpoint
+    G, D, _, _ = make_models(awm, dev)
+    G.train(); D.train()
+    opt = torch.optim.Adam(list(G.parameters()) + list(D.parameters()), lr=1e-3)
+    s = O.synthetic_clips(2, seed=8, T=1024).to(dev)
+    msg = O.synthetic_messages(2, seed=9).to(dev)
+    awm.train_step(G, D, opt, s, msg)
+    pth = str(tmp_path / "ckpt_latest.pth")
+    checkpoint.save_resumable(pth, 0, 1, 1.0, G, D, opt)
+    for st in opt.state.values():
+        assert st["exp_avg"].is_cuda and st["exp_avg_sq"].is_cuda
+    awm.train_step(G, D, opt, s, msg)                                        # would raise a device mismatch otherwise
+    ck = torch.load(pth, weights_only=True)
+    assert all(not v["exp_avg"].is_cuda for v in ck["opt"]["state"].values())
+    G2, D2, _, _ = make_models(awm, dev)
+    opt2 = torch.optim.Adam(list(G2.parameters()) + list(D2.parameters()), lr=1e-3)
+    assert checkpoint.load_resumable(pth, G2, D2, opt2) == (0, 1, 1.0)
+    assert float(opt2.state_dict()["state"][0]["step"]) == 1.0
+
+
 def test_conv_bf16x6_is_fp32_grade(awm, dev):
     """the bf16x6 split build of the k3 convolution carries the same error as the native fp32 MFMA build (vs fp64)"""
     from awm_amd import ops
@@ -992,7 +1138,7 @@ def test_evaluate_unseen_file_and_detect_prob(awm, dev, tmp_path):
     D2.load_state_dict({k: torch.from_numpy(ck[k]) for k in ck.files})
     D2.to(dev).eval()               # like the reference's detect_prob, ours uses the module in the mode the caller left it in
     path = str(tmp_path / "clip.wav")
-    awm.save_audio(path, w)
+    awm.save_audio(w, path, lowpass_hz=None)
     wq = awm.load_audio(path)
     pq = awm.detect_prob(path, D2, device=dev)
     assert abs(pq - O.detect_prob_waveform({k: torch.from_numpy(ck[k]) for k in ck.files}, wq)) <= 1e-4 * pq + 1e-7
