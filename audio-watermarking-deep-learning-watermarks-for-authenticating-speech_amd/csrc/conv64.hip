@@ -2911,8 +2911,10 @@ int launch_wgrad64bf7(const Wgrad64Args& a, int* grid_out, hipStream_t stream) {
 // autograd).  Both read the same gradient frames (dz, and y for the BatchNorm-backward rebuild g = A dz + B + C y): as two
 // launches the pair moves 7 frames, fused 4 (conv2: dz2 y2 y1 in, dz1 out) or 5 (conv1: dz1 y1 x dz2 in, dx out).
 // A workgroup walks 64-step tiles.  The staging thread holds two channels x four steps of the gradient, rebuilds g once and
-// splits it twice: time pairs into the [channel][time] image of the weight gradient (phase A), channel pairs into the
-// [time][channel] image of the data gradient (phase B).  Per tile and wave:
+// splits it once: time pairs of bf16 pieces go into the [channel][time] image of the weight gradient (phase A); the
+// [time][channel] image of the data gradient takes channel pairs, which are the same pieces re-paired by v_perm (phase B).
+// The data gradient is accumulated transposed (rows = time, columns = channel), so that a lane's accumulator quads are four
+// consecutive steps of one channel: epilogue operand and result move as dwordx4.  Per tile and wave:
 //   phase A: 72 MFMAs of the data gradient (weight fragments of its 32 output rows resident in registers, as conv64bf3)
 //            out of image D(i); side work: tile i+1 -> images G'(i+1), X'(i+1) (double-buffered), the epilogue operand of tile i
 //   barrier
@@ -2970,7 +2972,8 @@ __global__ __launch_bounds__(256) void dwgrad64bf_kernel(DWArgs a) {
     const int cp = wave * 8 + (lane & 7), c0 = 2 * cp, q0 = lane >> 3;
     const int hc = (tid & 127) >> 1, hh = tid & 1;
     float4 ra_[2], rb_[2], ya_[2], yb_[2], xa_[2], xb_[2];     // raw, per unit: dz / y of channel c0 (a) and c0 + 1 (b); x of both
-    float4 ga_[2], gb_[2];                                     // the rebuilt gradient of the tile being split (phase A -> phase B)
+    float4 gz_;                                                // the rebuilt gradient of the (unit, channel) being split
+    unsigned gp_[2][2][6];                                     // its bf16 pieces [unit][channel][piece * 2 + time pair] (phase A -> phase B)
     float hg = 0.f, hy = 0.f, hxv = 0.f;
     wm_srd_t dsg = make_srd(a.g, 0), dsy = dsg, dsx = dsg;
     unsigned voff = 0, hoff = 0;
@@ -3056,17 +3059,19 @@ __global__ __launch_bounds__(256) void dwgrad64bf_kernel(DWArgs a) {
         vc -= __uint_as_float(r1 << 16); vd -= __uint_as_float(r1 & 0xffff0000u);
         asm volatile("" : "+v"(vc), "+v"(vd), "+v"(r1));
     };
+    unsigned l0 = 0, l1 = 0;
     auto out4 = [&](unsigned short* dst, int stride_p) {         // two time pairs of one channel row: 8-byte writes
         const bf16x2 la = {(__bf16)va, (__bf16)vb}, lb = {(__bf16)vc, (__bf16)vd};
+        l0 = __builtin_bit_cast(unsigned, la); l1 = __builtin_bit_cast(unsigned, lb);
         *reinterpret_cast<uint2*>(dst) = make_uint2(p0, r0);
         *reinterpret_cast<uint2*>(dst + stride_p) = make_uint2(p1, r1);
-        *reinterpret_cast<uint2*>(dst + 2 * stride_p) = make_uint2(__builtin_bit_cast(unsigned, la), __builtin_bit_cast(unsigned, lb));
+        *reinterpret_cast<uint2*>(dst + 2 * stride_p) = make_uint2(l0, l1);
     };
     // gradient rebuild of channel j of unit u from the raw staging registers (free for the refill afterwards): one value per slice
     // (a slice must stay within the shadow of one MFMA, about seven instructions: a twelve-instruction slice costs its excess in full)
     auto g_build = [&](int u, int j, int e) {
         const float4 dz = j ? rb_[u] : ra_[u], yy = j ? yb_[u] : ya_[u];
-        float4& gz = j ? gb_[u] : ga_[u];
+        float4& gz = gz_;
         const float d = (e == 0) ? dz.x : (e == 1) ? dz.y : (e == 2) ? dz.z : dz.w;
         const float yv = (e == 0) ? yy.x : (e == 1) ? yy.y : (e == 2) ? yy.z : yy.w;
         float v = pro_apply<PRO_BNBWD>(d, yv, kga[j], kgb[j], kgc[j], kgl[j]);
@@ -3075,7 +3080,7 @@ __global__ __launch_bounds__(256) void dwgrad64bf_kernel(DWArgs a) {
         if (e == 0) gz.x = v; else if (e == 1) gz.y = v; else if (e == 2) gz.z = v; else gz.w = v;
     };
     auto g_pick_t = [&](int u, int j) {                         // time pairs of channel j of unit u
-        const float4 gz = j ? gb_[u] : ga_[u];
+        const float4 gz = gz_;
         va = gz.x; vb = gz.y; vc = gz.z; vd = gz.w;
         asm volatile("" : "+v"(va), "+v"(vb), "+v"(vc), "+v"(vd));
     };
@@ -3088,17 +3093,17 @@ __global__ __launch_bounds__(256) void dwgrad64bf_kernel(DWArgs a) {
         va = xx.x; vb = xx.y; vc = xx.z; vd = xx.w;
         asm volatile("" : "+v"(va), "+v"(vb), "+v"(vc), "+v"(vd));
     };
-    auto g_pick_c = [&](int u, int e) {                         // channel pair (c0, c0 + 1) at time step e of unit u
-        const float4 A = ga_[u], Bv = gb_[u];
-        va = (e == 0) ? A.x : (e == 1) ? A.y : (e == 2) ? A.z : A.w;
-        vb = (e == 0) ? Bv.x : (e == 1) ? Bv.y : (e == 2) ? Bv.z : Bv.w;
-        asm volatile("" : "+v"(va), "+v"(vb));
-    };
+    // image D wants channel pairs (c0, c0 + 1) at ONE time step; the pieces of a value do not depend on what it is paired with, so
+    // they are taken from the time-pair dwords of the two channels with one v_perm each instead of splitting the gradient again
     auto d_out = [&](int u, int e) {
-        const bf16x2 la = {(__bf16)va, (__bf16)vb};
+        const unsigned sel = (e & 1) ? 0x07060302u : 0x05040100u;   // high | low halves of (channel c0 + 1 : channel c0)
+        const int pr = e >> 1;
+        const unsigned d0 = __builtin_amdgcn_perm(gp_[u][1][pr], gp_[u][0][pr], sel);
+        const unsigned d1 = __builtin_amdgcn_perm(gp_[u][1][2 + pr], gp_[u][0][2 + pr], sel);
+        const unsigned d2 = __builtin_amdgcn_perm(gp_[u][1][4 + pr], gp_[u][0][4 + pr], sel);
         unsigned* D32 = reinterpret_cast<unsigned*>(Db);
         const int o = (1 + 4 * (q0 + 8 * u) + e) * (PITCH / 2) + cp;
-        D32[o] = p0; D32[(ROWS * PITCH >> 1) + o] = p1; D32[2 * (ROWS * PITCH >> 1) + o] = __builtin_bit_cast(unsigned, la);
+        D32[o] = d0; D32[(ROWS * PITCH >> 1) + o] = d1; D32[2 * (ROWS * PITCH >> 1) + o] = d2;
     };
     // halos: the gradient's for image D (rows 0 and 65), the input operand's for image X' (elements XO - 1, XO + 64)
     auto hx_pick = [&]() {
@@ -3139,7 +3144,10 @@ __global__ __launch_bounds__(256) void dwgrad64bf_kernel(DWArgs a) {
             if (st == 5) s1a();
             if (st == 6) { s2a(); s1b(); }
             if (st == 7) s2b();
-            if (st == 8) out4(G + (c0 + j) * PG + 4 * (q0 + 8 * u), 64 * PG);
+            if (st == 8) {
+                out4(G + (c0 + j) * PG + 4 * (q0 + 8 * u), 64 * PG);
+                gp_[u][j][0] = p0; gp_[u][j][1] = r0; gp_[u][j][2] = p1; gp_[u][j][3] = r1; gp_[u][j][4] = l0; gp_[u][j][5] = l1;
+            }
         } else if (v < 60) {
             const int w = v - 36, uj = w / 6, st = w % 6, u = uj >> 1, j = uj & 1;
             if (st == 0) x_pick_t(u, j);
@@ -3156,17 +3164,14 @@ __global__ __launch_bounds__(256) void dwgrad64bf_kernel(DWArgs a) {
             if (st == 3) hx_out(X);
         }
     };
-    // phase-B side work, slice v of 36: the rebuilt gradient -> image D (channel-pair split), then the refill
-    //   v 0..31  per (unit, time step) 4 slices: pick | hi | mid | lo + write;   v 32..35 gradient halo
+    // phase-B side work, slice v of 12: the gradient's pieces -> image D (channel pairs by v_perm)
+    //   v 0..7  one slice per (unit, time step): 3 perms + 3 writes;   v 8..11 gradient halo
+    constexpr int NSB = 12;
     auto sideB = [&](int v) __attribute__((always_inline)) {
-        if (v < 32) {
-            const int ue = v >> 2, st = v & 3, u = ue >> 2, e = ue & 3;
-            if (st == 0) g_pick_c(u, e);
-            if (st == 1) s1a();
-            if (st == 2) s2a();
-            if (st == 3) d_out(u, e);
+        if (v < 8) {
+            d_out(v >> 2, v & 3);
         } else {
-            const int st = v - 32;
+            const int st = v - 8;
             if (st == 0) { hg_pick(); load_ghalo(); }
             if (st == 1) s1a();
             if (st == 2) s2a();
@@ -3179,7 +3184,7 @@ __global__ __launch_bounds__(256) void dwgrad64bf_kernel(DWArgs a) {
 #pragma unroll
         for (int v = 0; v < NSA; ++v) sideA(v, Gb0, Xb0);
 #pragma unroll
-        for (int v = 0; v < 36; ++v) sideB(v);
+        for (int v = 0; v < NSB; ++v) sideB(v);
         okh_cur = okh_n;
     }
     __syncthreads();
@@ -3189,19 +3194,13 @@ __global__ __launch_bounds__(256) void dwgrad64bf_kernel(DWArgs a) {
     for (int k = 0; k < KW; ++k)
 #pragma unroll
         for (int r = 0; r < 16; ++r) wacc[k][r] = 0.f;
-    float s1[STATS ? 16 : 1], s2[STATS ? 16 : 1];
-    if (STATS) {
-#pragma unroll
-        for (int j = 0; j < 16; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
-    }
-    float e1r[16];
-    // ReLU-mask constants of this lane's 16 accumulator rows, in registers: an LDS read inside an epilogue slice would stall the
-    // wave for the whole LDS latency in front of the next MFMA (measured: +1.3 K cycles per tile)
-    float kea[EPI == EPI_RELUMASK ? 16 : 1], keb[EPI == EPI_RELUMASK ? 16 : 1];
-    if (EPI == EPI_RELUMASK) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { kea[r] = Cs[384 + 32 * mt + mfma_row(r, half)]; keb[r] = Cs[448 + 32 * mt + mfma_row(r, half)]; }
-    }
+    // The data gradient is accumulated TRANSPOSED (gradient image = A operand, weights = B operand): a lane then owns ONE output
+    // channel (32 mt + l31) and, per accumulator quad, four consecutive time steps -- the epilogue operand comes in and the
+    // result goes out as dwordx4 (8 memory instructions per tile instead of 32), the ReLU-mask constants and the two BatchNorm
+    // sums are one register each instead of sixteen.
+    float s1 = 0.f, s2 = 0.f;
+    f32x4 e1q[4];
+    const float kea = (EPI == EPI_RELUMASK) ? Cs[384 + 32 * mt + l31] : 0.f, keb = (EPI == EPI_RELUMASK) ? Cs[448 + 32 * mt + l31] : 0.f;
     int buf = 0;
 #ifdef WM_STAMP
     unsigned long long tm[6] = {0, 0, 0, 0, 0, 0};
@@ -3217,18 +3216,20 @@ __global__ __launch_bounds__(256) void dwgrad64bf_kernel(DWArgs a) {
         const unsigned short* Xc = Xb0 + buf * XIMG;
         unsigned short* Gn = Gb0 + (buf ^ 1) * GIMG;
         unsigned short* Xn = Xb0 + (buf ^ 1) * XIMG;
-        // data-gradient output / epilogue operand of this lane: rows 32 mt + (r & 3) + 8 (r >> 2) + 4 half, column t0 + 32 nh + l31
+        // data-gradient output / epilogue operand of this lane: channel 32 mt + l31, steps t0 + 32 nh + 8 q + 4 half + (0..3) for quad q
         const size_t slab = ((size_t)b * 64 + 32 * mt) * T;
         const wm_srd_t sye = make_srd(a.y + slab, (size_t)32 * T * sizeof(float));
         const wm_srd_t se1 = make_srd(a.e1 + slab, (size_t)32 * T * sizeof(float));
-        const unsigned eoff = (unsigned)(4 * half * T + t0 + 32 * nh + l31) * 4u;
-        auto roff = [&](int r) { return (unsigned)(((r & 3) + 8 * (r >> 2)) * T) * 4u; };
+        const unsigned eoff = (unsigned)(l31 * T + t0 + 32 * nh + 4 * half) * 4u;
 
         STAMP(ts0);
         // ---------------- phase A: data gradient out of image D
         f32x16 dacc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) dacc[r] = 0.f;
+        // the data-gradient accumulator in VGPRs: left to the allocator it shares a[0:15] with one weight-gradient accumulator,
+        // which is then copied out and back around every phase A (48 v_accvgpr moves per tile), and the epilogue reads it directly
+        asm volatile("" : "+v"(dacc));
         {
             const unsigned short* drow = Db + (32 * nh + l31) * PITCH + 8 * half;
             bf16x8 Bq[2][NP];
@@ -3246,11 +3247,11 @@ __global__ __launch_bounds__(256) void dwgrad64bf_kernel(DWArgs a) {
                 for (int j = 0; j < 6; ++j) {
                     const int pa = (j == 0 || j == 4) ? 1 : (j == 2 ? 2 : 0), pb = (j == 0 || j == 3) ? 1 : (j == 1 ? 2 : 0);
                     FENCE;
-                    dacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wr[s][pa], Bf[pb], dacc, 0, 0, 0);
+                    dacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Bf[pb], Wr[s][pa], dacc, 0, 0, 0);      // D^T: rows = time, columns = channel
                     FENCE;
                     const int m = s * 6 + j;                         // 0..71
                     if (m < NSA) sideA(m, Gn, Xn);
-                    else { e1r[2 * (m - NSA)] = buf_load(se1, eoff, roff(2 * (m - NSA))); e1r[2 * (m - NSA) + 1] = buf_load(se1, eoff, roff(2 * (m - NSA) + 1)); }
+                    else if (((m - NSA) & 1) == 0) e1q[(m - NSA) >> 1] = buf_load4(se1, eoff + 32u * ((m - NSA) >> 1), 0u);
                     FENCE;
                 }
             }
@@ -3289,18 +3290,27 @@ __global__ __launch_bounds__(256) void dwgrad64bf_kernel(DWArgs a) {
                 asm volatile("" : "+v"(s_.x), "+v"(s_.y), "+v"(s_.z), "+v"(s_.w));
                 Br[p] = __builtin_bit_cast(bf16x8, s_);
             };
-            // epilogue of accumulator row r of the data gradient
-            auto epi = [&](int r) {
-                float v = dacc[r];
-                if (EPI == EPI_RELUMASK) {
-                    const float qv = e1r[r];
-                    v = (fmaf(qv, kea[r], keb[r]) > 0.f) ? v : 0.f;
-                    s1[r] += v; s2[r] = fmaf(v, qv, s2[r]);
-                    asm volatile("" : "+v"(s1[r]), "+v"(s2[r]));
-                } else {
-                    v += e1r[r];
+            // epilogue of accumulator registers 2 i, 2 i + 1 of the data gradient (two time steps of the lane's channel); every second
+            // call completes a quad and stores it
+            auto epi2 = [&](int i) {
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int r = 2 * i + e;
+                    float v = dacc[r];
+                    const float qv = e1q[r >> 2][r & 3];
+                    if (EPI == EPI_RELUMASK) {
+                        v = (fmaf(qv, kea, keb) > 0.f) ? v : 0.f;
+                        s1 += v; s2 = fmaf(v, qv, s2);
+                        asm volatile("" : "+v"(s1), "+v"(s2));
+                    } else {
+                        v += qv;
+                    }
+                    dacc[r] = v;
                 }
-                buf_store(sye, v, eoff, roff(r));
+                if (i & 1) {
+                    const int q4 = i >> 1;
+                    buf_store4(sye, f32x4{dacc[4 * q4], dacc[4 * q4 + 1], dacc[4 * q4 + 2], dacc[4 * q4 + 3]}, eoff + 32u * q4, 0u);
+                }
             };
             read_kb(0, 0);
 #pragma unroll
@@ -3320,9 +3330,10 @@ __global__ __launch_bounds__(256) void dwgrad64bf_kernel(DWArgs a) {
                 if (mm < 3) shl(set, mm);
                 else if (mm < 6) shr(set, mm - 3);
                 else {
+                    // 48 free slices: image D of the next tile in every second one of the first 24, the epilogue quads in the last 24
                     const int v = kb * 12 + (mm - 6);             // 0..47
-                    if (v < 36) sideB(v);
-                    else if (v < 44) { epi(2 * (v - 36)); epi(2 * (v - 36) + 1); }
+                    if (v < 2 * NSB) { if ((v & 1) == 0) sideB(v >> 1); }
+                    else if (v >= 24 && ((v - 24) % 3) == 0) epi2((v - 24) / 3);
                 }
                 if (mm == 12 && kb + 1 < 4) read_kb(kb + 1, set ^ 1);
                 FENCE;
@@ -3361,16 +3372,11 @@ __global__ __launch_bounds__(256) void dwgrad64bf_kernel(DWArgs a) {
     }
     if (STATS) {
         float* red = reinterpret_cast<float*>(smem_raw);          // [2 column halves][2][64]
-#pragma unroll
-        for (int j = 0; j < 16; ++j) { s1[j] = half_wave_sum(s1[j]); s2[j] = half_wave_sum(s2[j]); }
+        s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);       // the two time halves of the lane's channel
         __syncthreads();
-        if (l31 == 0) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = 32 * mt + mfma_row(r, half);
-                red[nh * 128 + co] = s1[r];
-                red[nh * 128 + 64 + co] = s2[r];
-            }
+        if (half == 0) {
+            red[nh * 128 + 32 * mt + l31] = s1;
+            red[nh * 128 + 64 + 32 * mt + l31] = s2;
         }
         __syncthreads();
         if (tid < 128) a.stats[(size_t)blockIdx.x * 128 + tid] = red[tid] + red[128 + tid];

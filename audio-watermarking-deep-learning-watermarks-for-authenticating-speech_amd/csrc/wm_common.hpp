@@ -170,6 +170,9 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f32x4 buf_load4(wm_srd_t srd, unsigned voff_bytes, unsigned soff_bytes) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd, (int)voff_bytes, (int)soff_bytes, 0));
 }
+__device__ __forceinline__ void buf_store4(wm_srd_t srd, f32x4 v, unsigned voff_bytes, unsigned soff_bytes) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), srd, (int)voff_bytes, (int)soff_bytes, 0);
+}
 __device__ __forceinline__ void buf_store(wm_srd_t srd, float v, unsigned voff_bytes, unsigned soff_bytes) {
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), srd, (int)voff_bytes, (int)soff_bytes, 0);
 }

@@ -110,6 +110,8 @@ class GradSync:
         self._pending = self._n_early
 
     def _on_accumulated(self, _param):
+        if not self.enabled():                        # single process: nothing to exchange, nothing to count
+            return
         self._pending -= 1
         if self._pending < 0 or (self._pending == 0 and self._work is not None):
             raise RuntimeError("GradSync: a second backward reached the early-span hooks before the first one was exchanged "

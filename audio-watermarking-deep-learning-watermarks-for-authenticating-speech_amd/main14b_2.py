@@ -505,13 +505,17 @@ def train_step(generator, detector, optimizer, s, message, grad_sync=None):
     optimizer.zero_grad(set_to_none=not hasattr(optimizer, "flat"))
     if hasattr(grad_sync, "begin_step"):
         grad_sync.begin_step()
-    with ops.index_check_mode("deferred" if ops._CHECK_INDEX["mode"] == "sync" else ops._CHECK_INDEX["mode"]):
-        total, out = forward_losses(generator, detector, s, message)   # no mid-step sync (it would drain the launch queue)
-    total.backward()
-    if hasattr(optimizer, "finish_backward"):
-        optimizer.finish_backward()
-    if grad_sync is not None:
-        grad_sync()
-    ops.check_message_ids(wait=True, what="this train_step's batch")    # a bad id raises before the update (step.train_step)
+    try:
+        with ops.index_check_mode("deferred" if ops._CHECK_INDEX["mode"] == "sync" else ops._CHECK_INDEX["mode"]):
+            total, out = forward_losses(generator, detector, s, message)   # no mid-step sync (it would drain the launch queue)
+        total.backward()
+        if hasattr(optimizer, "finish_backward"):
+            optimizer.finish_backward()
+        if grad_sync is not None:
+            grad_sync()
+        ops.check_message_ids(wait=True, what="this train_step's batch")    # a bad id raises before the update (step.train_step)
+    except BaseException:
+        ops.drop_pending_message_checks()        # a step that died half-way must not report its flag inside a later, valid step
+        raise
     optimizer.step()
     return out

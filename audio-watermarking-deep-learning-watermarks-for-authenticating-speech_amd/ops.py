@@ -528,6 +528,11 @@ def check_message_ids(wait=True, what="an earlier Generator call"):
     _CHECK_INDEX["pending"] = keep
 
 
+def drop_pending_message_checks():
+    """forget deferred checks that have not been read yet (their step was abandoned)"""
+    _CHECK_INDEX["pending"] = []
+
+
 def _note_index_error(err, nrows):
     """err: int32 device tensor (non-zero = some id was out of range), handled according to the current mode"""
     mode = _CHECK_INDEX["mode"]

@@ -41,16 +41,20 @@ def train_step(generator, detector, optimizer, s, message, grad_sync=None):
     if hasattr(grad_sync, "begin_step"):
         grad_sync.begin_step()
     from . import ops
-    with ops.index_check_mode("deferred" if ops._CHECK_INDEX["mode"] == "sync" else ops._CHECK_INDEX["mode"]):
-        total, out = forward_losses(generator, detector, s, message)   # no mid-step sync for the message-id range check ...
-    total.backward()
-    if hasattr(optimizer, "finish_backward"):
-        optimizer.finish_backward()
-    if grad_sync is not None:
-        grad_sync()
-    # ... its flag (copied to pinned memory right after the lookup) has landed long before backward returns: read it here, so
-    # that a bad id raises BEFORE the update, as nn.Embedding's IndexError does (py/main16.py:158), never one step late
-    ops.check_message_ids(wait=True, what="this train_step's batch")
+    try:
+        with ops.index_check_mode("deferred" if ops._CHECK_INDEX["mode"] == "sync" else ops._CHECK_INDEX["mode"]):
+            total, out = forward_losses(generator, detector, s, message)   # no mid-step sync for the message-id range check ...
+        total.backward()
+        if hasattr(optimizer, "finish_backward"):
+            optimizer.finish_backward()
+        if grad_sync is not None:
+            grad_sync()
+        # ... its flag (copied to pinned memory right after the lookup) has landed long before backward returns: read it here, so
+        # that a bad id raises BEFORE the update, as nn.Embedding's IndexError does (py/main16.py:158), never one step late
+        ops.check_message_ids(wait=True, what="this train_step's batch")
+    except BaseException:
+        ops.drop_pending_message_checks()        # a step that died half-way must not report its flag inside a later, valid step
+        raise
     optimizer.step()
     return out
 

@@ -48,13 +48,18 @@ def force_sync_main(out_dir, n_total, T, model):
     opt = awm_amd.FlatAdam([G, D], lr=1e-3)
     s = O.synthetic_clips(n_total, seed=41, T=T).to(dev)
     msg = O.synthetic_messages(n_total, seed=42).to(dev)
-    snap = {k: v.clone() for m in (G, D) for k, v in m.state_dict().items()}
-    opt.zero_grad()
-    fwd(G, D, s, msg)[0].backward()
-    opt.finish_backward()
-    plain = opt.grad.clone()
-    for m in (G, D):                                         # BatchNorm running statistics back to where the plain run started
-        m.load_state_dict({k: snap[k] for k in m.state_dict()})
+    snap = {id(m): {k: v.clone() for k, v in m.state_dict().items()} for m in (G, D)}    # per module: G and D of main14b_2 share key names
+    plains = []
+    for _ in range(2):                                       # twice: the very first backward of a process must equal the second
+        opt.zero_grad()
+        fwd(G, D, s, msg)[0].backward()
+        opt.finish_backward()
+        plains.append(opt.grad.clone())
+        for m in (G, D):                                     # BatchNorm running statistics back to where the plain run started
+            m.load_state_dict(snap[id(m)])
+    plain = plains[1]
+    first_equal = torch.equal(plains[0], plains[1])
+    first_diff = float((plains[0] - plains[1]).abs().max())
     sync = wmd.GradSync(opt, early_modules=[D], force=True)
     assert sync.early is not None and sync.enabled()
     launched = []
@@ -72,6 +77,13 @@ def force_sync_main(out_dir, n_total, T, model):
     torch.cuda.synchronize()
     assert sync._work is None and sync._pending == sync._n_early
     same = torch.equal(opt.grad, plain)
+    where = []
+    if not same:                                             # name the parameters that differ (diagnostic for the assertion message)
+        names = [f"{n}.{k}" for n, m in (("G", G), ("D", D)) for k, _ in m.named_parameters()]
+        for (off, k), nm in zip(opt._spans, names):
+            d = float((opt.grad[off:off + k] - plain[off:off + k]).abs().max())
+            if d > 0:
+                where.append((nm, off, k, d, float(plain[off:off + k].abs().max())))
     # a backward that is never exchanged must not poison the next step: begin_step() (train_step calls it) discards it
     opt.zero_grad(); sync.begin_step()
     fwd(G, D, s, msg)[0].backward()
@@ -89,7 +101,8 @@ def force_sync_main(out_dir, n_total, T, model):
     sync.begin_step()
     torch.cuda.synchronize()
     torch.save({"same": same, "max_diff": float((opt.grad - plain).abs().max()) if not same else 0.0, "losses": losses,
-                "refused": refused, "early_span": sync.early, "bucket_bytes": 4 * opt.grad.numel()}, os.path.join(out_dir, "force_sync.pt"))
+                "refused": refused, "early_span": sync.early, "where": where,
+                "first_backward_equals_second": first_equal, "first_vs_second_max_diff": first_diff, "bucket_bytes": 4 * opt.grad.numel()}, os.path.join(out_dir, "force_sync.pt"))
     dist.destroy_process_group()
 
 

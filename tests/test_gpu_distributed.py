@@ -121,7 +121,8 @@ def test_gradsync_production_path_on_one_rank_rccl(tmp_path, model):
     T = 2048 if model == "main16" else 3200
     _spawn_ranks([os.path.join(ROOT, "tests", "dist_rehearsal.py"), str(tmp_path), "2", str(T), model, "force_sync"], world=1)
     r = torch.load(tmp_path / "force_sync.pt")
-    assert r["same"], r["max_diff"]
+    assert r["first_backward_equals_second"], ("the first backward of the process differs from the second", r["first_vs_second_max_diff"])
+    assert r["same"], (r["max_diff"], r["early_span"], r["where"][:12])
     assert r["refused"] and all(abs(a) < 1e6 for a in r["losses"])
     assert r["bucket_bytes"] == 4 * (4383314 if model == "main16" else 24893874)
 

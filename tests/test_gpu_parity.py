@@ -677,15 +677,43 @@ def _dft_logmel(x, n_fft=1024, hop=256):
     return torch.log(power @ fb + 1e-5)
 
 
-def test_all_grads_smooth_surrogate(awm, dev):
-    """test_all_grads_vs_oracle's 5e-3 floor is the LOSS, not a kernel: with the one term that is discontinuous in round-off
-    (F.l1_loss of log-mel differences of size ~1e-6: its gradient is a sum of signs) replaced by a smooth surrogate of the same
-    magnitude -- K x mean squared log-mel difference -- every parameter gradient of the SAME step (Generator, post-processing,
-    Detector, loud / loc / bce / l1 / hf terms through the HIP kernels) sits within max(2 x e_cpu, 3e-4 | 2e-3 biases) of the
-    fp64 run, in both convolution arithmetic modes."""
+class _relu_sites:
+    """context manager: torch.relu inside the oracle becomes `x * mask` with the masks of the HIP run, one per call in call order
+    (encoder.1 inner/outer, encoder.2, decoder.1, then model.1, model.2 of the Detector)"""
+
+    def __init__(self, masks):
+        self.masks, self.i = masks, 0
+
+    def __enter__(self):
+        self.orig = torch.relu
+
+        def masked(x):
+            m = self.masks[self.i]
+            self.i += 1
+            assert m.shape == x.shape, (m.shape, x.shape)
+            return x * m.to(x.dtype)
+        torch.relu = masked
+        return self
+
+    def __exit__(self, *exc):
+        torch.relu = self.orig
+        return False
+
+
+def test_all_grads_smooth_functional(awm, dev):
+    """What test_all_grads_vs_oracle's 5e-3 floor consists of, proven by removing it: the step's loss is a DISCONTINUOUS function of
+    round-off at (a) the sign inside F.l1_loss of log-mel differences of size ~1e-6 and (b) every ReLU whose pre-activation is
+    within round-off of zero -- ONE flipped element among the B*T = 12 288 terms of a weight-gradient sum moves that gradient by
+    ~1/sqrt(B*T) of its size, i.e. ~3e-3 of max (exactly the G.encoder.1.block.3 / block.4 / encoder.0 signature the full-loss test
+    shows).  Here both are pinned: (a) the mel term is replaced by a smooth surrogate of the same magnitude (K x mean squared
+    log-mel difference), (b) the CPU runs (fp64 'truth' and the fp32 yardstick) use the ReLU masks the HIP forward actually took
+    (read back from the HIP modules: block outputs and the saved pre-BN activations).  The three runs then differentiate the SAME
+    smooth function, and every parameter gradient of the HIP path -- Generator incl. all T LSTM steps, post-processing, Detector,
+    loud / loc / bce / l1 / hf terms, fused data+weight-gradient kernels (T % 64 == 0) -- must sit within
+    max(2 x e_cpu, 3e-4 | 2e-3 for biases) of the fp64 run, in both convolution arithmetic modes."""
     from awm_amd import ops
     from awm_amd.step import LOSS_WEIGHTS as W
-    B, T = 3, 4000
+    B, T = 3, 4096
     gsd, dsd = states()
     msg = O.synthetic_messages(B, seed=71)
     for seed in range(70, 170):      # keep every sample away from clamp_peak's derivative discontinuity
@@ -695,30 +723,53 @@ def test_all_grads_smooth_surrogate(awm, dev):
         if float((f.abs() - 0.02).abs().min()) >= 1e-5 * float(f.abs().max()):
             break
 
-    def cpu_run(dtype):
+    def hip_run():
+        G, D, _, _ = make_models(awm, dev, gsd, dsd)
+        G.train(); D.train()
+        sites, hooks = [], []
+
+        def grab(_mod, _inp, out):
+            x, y1, y2, mask, cst = out.grad_fn.saved_tensors[:5]
+            inner = torch.addcmul(cst[1].double()[None, :, None], y1.double(), cst[0].double()[None, :, None]) > 0   # relu(BN1(conv1 x))
+            sites.append(inner.cpu()); sites.append((out > 0).cpu())
+        for m in (G.encoder[1], G.encoder[2], G.decoder[1], D.model[1], D.model[2]):
+            hooks.append(m.register_forward_hook(grab))
+        _, out = awm.forward_losses(G, D, s.to(dev), msg.to(dev))
+        for h in hooks:
+            h.remove()
+        assert len(sites) == 10
+        return G, D, out, sites
+
+    def cpu_run(dtype, sites):
         g = {k: (v.to(dtype) if v.is_floating_point() else v).clone().requires_grad_(v.dtype.is_floating_point and "running" not in k) for k, v in gsd.items()}
         d = {k: (v.to(dtype) if v.is_floating_point() else v).clone().requires_grad_(v.dtype.is_floating_point and "running" not in k) for k, v in dsd.items()}
-        _, o = O.step_losses(g, d, s.to(dtype), msg, training=True, g_stats={}, d_stats={})
+        with _relu_sites(sites) as rs:
+            _, o = O.step_losses(g, d, s.to(dtype), msg, training=True, g_stats={}, d_stats={})
+            assert rs.i == 10
         msq = ((_dft_logmel(s.to(dtype)) - _dft_logmel(o["s_w"])) ** 2).mean()
         return g, d, o, msq
-    g2, d2, o2, msq2 = cpu_run(torch.float64)
-    K = float(o2["mel"].detach() / msq2.detach())                           # surrogate term as large as the term it replaces
 
-    def total_of(o, msq):
+    def total_of(o, msq, K):
         return W["l1"] * o["l1"] + W["mel"] * K * msq + W["loud"] * o["loud"] + W["loc"] * o["loc"] + W["bce"] * o["bce"] + W["hf"] * o["hf"]
-    total_of(o2, msq2).backward()
-    g3, d3, o3, msq3 = cpu_run(torch.float32)
-    total_of(o3, msq3).backward()
     prev = ops.conv_bf16x6()
     try:
         for mode in (True, False):
             ops.set_conv_bf16x6(mode)
-            G, D, _, _ = make_models(awm, dev, gsd, dsd)
-            G.train(); D.train()
-            _, out = awm.forward_losses(G, D, s.to(dev), msg.to(dev))
+            G, D, out, sites = hip_run()
+            g2, d2, o2, msq2 = cpu_run(torch.float64, sites)
+            K = float(o2["mel"].detach() / msq2.detach())                       # surrogate term as large as the term it replaces
+            total_of(o2, msq2, K).backward()
+            g3, d3, o3, msq3 = cpu_run(torch.float32, sites)
+            total_of(o3, msq3, K).backward()
+            # how many ReLU decisions of the HIP forward differ from a free fp64 forward (informative: these are the flips)
+            with torch.no_grad():
+                _, of = O.step_losses({k: v.double() if v.is_floating_point() else v for k, v in gsd.items()},
+                                      {k: v.double() if v.is_floating_point() else v for k, v in dsd.items()}, s.double(), msg,
+                                      training=True, g_stats={}, d_stats={})
+            check(out["delta_raw"], of["delta_raw"], FWD_TOL, "delta_raw vs the free fp64 forward")
             msq = ((_dft_logmel(s.to(dev)) - _dft_logmel(out["s_w"])) ** 2).mean()
             check(msq.reshape(1), msq2.reshape(1), 1e-3, "surrogate value")
-            total_of(out, msq).backward()
+            total_of(out, msq, K).backward()
             table = []
             for name, mod, ref, c32 in (("G", G, g2, g3), ("D", D, d2, d3)):
                 for k, p in mod.named_parameters():
@@ -733,9 +784,9 @@ def test_all_grads_smooth_surrogate(awm, dev):
                         floor = GRAD_FLOOR_BIAS
                     table.append((e / max(2.0 * e_cpu, floor), f"{name}.{k}", e, e_cpu))
             bad = [t for t in table if t[0] > 1.0]
-            assert not bad, "smooth-loss gradients outside max(2 x e_cpu, %g) (ratio, name, hip-vs-fp64, cpu32-vs-fp64), bf16x6=%s: %s" % (
+            assert not bad, "smooth-functional gradients outside max(2 x e_cpu, %g) (ratio, name, hip-vs-fp64, cpu32-vs-fp64), bf16x6=%s: %s" % (
                 GRAD_FLOOR, mode, sorted(bad, reverse=True)[:8])
-            print("smooth surrogate: worst ratio to the bar", max(t[0] for t in table), "bf16x6 =", mode)
+            print("smooth functional: worst ratio to the bar", max(t[0] for t in table), "bf16x6 =", mode)
     finally:
         ops.set_conv_bf16x6(prev)
 
@@ -772,7 +823,7 @@ def test_bad_message_id_never_reaches_the_update(awm, dev):
     G, D, _, _ = make_models(awm, dev)
     G.train(); D.train()
     opt = awm.FlatAdam([G, D], lr=1e-3)
-    s = O.synthetic_clips(2, seed=5, T=1024).to(dev)
+    s = O.synthetic_clips(2, seed=5, T=4096).to(dev)
     before = opt.flat.clone()
     with pytest.raises(IndexError, match="this train_step"):
         awm.train_step(G, D, opt, s, torch.tensor([3, 65536], device=dev))
@@ -789,7 +840,7 @@ def test_resumable_checkpoint_leaves_torch_adam_on_the_gpu(awm, dev, tmp_path):
     G, D, _, _ = make_models(awm, dev)
     G.train(); D.train()
     opt = torch.optim.Adam(list(G.parameters()) + list(D.parameters()), lr=1e-3)
-    s = O.synthetic_clips(2, seed=8, T=1024).to(dev)
+    s = O.synthetic_clips(2, seed=8, T=4096).to(dev)
     msg = O.synthetic_messages(2, seed=9).to(dev)
     awm.train_step(G, D, opt, s, msg)
     pth = str(tmp_path / "ckpt_latest.pth")
