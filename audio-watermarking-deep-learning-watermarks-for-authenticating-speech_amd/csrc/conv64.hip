@@ -3000,6 +3000,26 @@ __global__ __launch_bounds__(256) void dwgrad64bf_kernel(DWArgs a) {
         xa_[u] = __builtin_bit_cast(float4, buf_load4(dsx, voff + 128u * u, 0u));
         xb_[u] = __builtin_bit_cast(float4, buf_load4(dsx, voff + 128u * u, rowT));
     };
+    // The refills of the raw staging registers are dealt ONE load at a time over both phases (a register set is free from the slice
+    // that consumed it until the same slice of the next tile): a burst of four 1-KB loads from one wave stalls that wave at issue
+    // whenever the CU's miss queue is full, a different wave every tile -- measured as 430 of 8 250 cycles per tile spent at the
+    // phase-A barrier waiting for whichever wave was hit.
+    auto refillA = [&](int m) {                     // phase-A slice m
+        if (m == 14) ra_[0] = __builtin_bit_cast(float4, buf_load4(dsg, voff, 0u));
+        if (m == 20) rb_[0] = __builtin_bit_cast(float4, buf_load4(dsg, voff, rowT));
+        if (m == 26) ya_[0] = __builtin_bit_cast(float4, buf_load4(dsy, voff, 0u));
+        if (m == 32) yb_[0] = __builtin_bit_cast(float4, buf_load4(dsy, voff, rowT));
+        if (m == 38) ra_[1] = __builtin_bit_cast(float4, buf_load4(dsg, voff + 128u, 0u));
+        if (m == 44) rb_[1] = __builtin_bit_cast(float4, buf_load4(dsg, voff + 128u, rowT));
+        if (m == 50) ya_[1] = __builtin_bit_cast(float4, buf_load4(dsy, voff + 128u, 0u));
+        if (m == 56) yb_[1] = __builtin_bit_cast(float4, buf_load4(dsy, voff + 128u, rowT));
+    };
+    auto refillB = [&](int v) {                     // phase-B free slice v
+        if (v == 1) xa_[0] = __builtin_bit_cast(float4, buf_load4(dsx, voff, 0u));
+        if (v == 7) xb_[0] = __builtin_bit_cast(float4, buf_load4(dsx, voff, rowT));
+        if (v == 13) xa_[1] = __builtin_bit_cast(float4, buf_load4(dsx, voff + 128u, 0u));
+        if (v == 19) xb_[1] = __builtin_bit_cast(float4, buf_load4(dsx, voff + 128u, rowT));
+    };
     auto load_ghalo = [&]() { hg = buf_load(dsg, hoff, 0u); hy = buf_load(dsy, hoff, 0u); };
     auto load_xhalo = [&]() { hxv = buf_load(dsx, hoff, 0u); };
 
@@ -3140,7 +3160,7 @@ __global__ __launch_bounds__(256) void dwgrad64bf_kernel(DWArgs a) {
         if (v < 36) {
             const int uj = v / 9, st = v % 9, u = uj >> 1, j = uj & 1;
             if (st < 4) g_build(u, j, st);
-            if (st == 4) { g_pick_t(u, j); if (j == 1) load_g(u); }          // both channels of the unit rebuilt: refill its raw registers
+            if (st == 4) g_pick_t(u, j);
             if (st == 5) s1a();
             if (st == 6) { s2a(); s1b(); }
             if (st == 7) s2b();
@@ -3151,7 +3171,7 @@ __global__ __launch_bounds__(256) void dwgrad64bf_kernel(DWArgs a) {
         } else if (v < 60) {
             const int w = v - 36, uj = w / 6, st = w % 6, u = uj >> 1, j = uj & 1;
             if (st == 0) x_pick_t(u, j);
-            if (st == 1) { s1a(); if (j == 1) load_x(u); }
+            if (st == 1) s1a();
             if (st == 2) s2a();
             if (st == 3) s1b();
             if (st == 4) s2b();
@@ -3182,9 +3202,9 @@ __global__ __launch_bounds__(256) void dwgrad64bf_kernel(DWArgs a) {
         set_tile(min(tile + tstep, ntiles - 1));
         const bool okh_n = okh;
 #pragma unroll
-        for (int v = 0; v < NSA; ++v) sideA(v, Gb0, Xb0);
+        for (int v = 0; v < NSA; ++v) { sideA(v, Gb0, Xb0); refillA(v); }
 #pragma unroll
-        for (int v = 0; v < NSB; ++v) sideB(v);
+        for (int v = 0; v < 2 * NSB; ++v) { if ((v & 1) == 0) sideB(v >> 1); else refillB(v); }
         okh_cur = okh_n;
     }
     __syncthreads();
@@ -3227,9 +3247,6 @@ __global__ __launch_bounds__(256) void dwgrad64bf_kernel(DWArgs a) {
         f32x16 dacc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) dacc[r] = 0.f;
-        // the data-gradient accumulator in VGPRs: left to the allocator it shares a[0:15] with one weight-gradient accumulator,
-        // which is then copied out and back around every phase A (48 v_accvgpr moves per tile), and the epilogue reads it directly
-        asm volatile("" : "+v"(dacc));
         {
             const unsigned short* drow = Db + (32 * nh + l31) * PITCH + 8 * half;
             bf16x8 Bq[2][NP];
@@ -3243,6 +3260,9 @@ __global__ __launch_bounds__(256) void dwgrad64bf_kernel(DWArgs a) {
                         Bq[(s + 1) & 1][p] = *reinterpret_cast<const bf16x8*>(drow + (p * ROWS + ((s + 1) >> 2)) * PITCH + 16 * ((s + 1) & 3));
                 }
                 const bf16x8* Bf = Bq[s & 1];
+                // the weight-gradient accumulators stay where they are across this phase: left alone, the allocator lends a[0:15] of
+                // one of them to dacc and copies it out and back around every phase A (32 v_accvgpr moves per tile)
+                if ((s & 3) == 1) asm volatile("" : "+a"(wacc[0]), "+a"(wacc[1]), "+a"(wacc[2]));
 #pragma unroll
                 for (int j = 0; j < 6; ++j) {
                     const int pa = (j == 0 || j == 4) ? 1 : (j == 2 ? 2 : 0), pb = (j == 0 || j == 3) ? 1 : (j == 1 ? 2 : 0);
@@ -3250,14 +3270,20 @@ __global__ __launch_bounds__(256) void dwgrad64bf_kernel(DWArgs a) {
                     dacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Bf[pb], Wr[s][pa], dacc, 0, 0, 0);      // D^T: rows = time, columns = channel
                     FENCE;
                     const int m = s * 6 + j;                         // 0..71
-                    if (m < NSA) sideA(m, Gn, Xn);
+                    if (m < NSA) { sideA(m, Gn, Xn); refillA(m); }
                     else if (((m - NSA) & 1) == 0) e1q[(m - NSA) >> 1] = buf_load4(se1, eoff + 32u * ((m - NSA) >> 1), 0u);
                     FENCE;
                 }
             }
         }
         STAMP(ts1);
+#ifdef WM_STAMP
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        STAMP(ts1b);
+        asm volatile("s_barrier" ::: "memory");
+#else
         lds_barrier();          // every wave is done with image D; images G', X' of the next tile are complete
+#endif
         STAMP(ts2);
         // ---------------- phase B: weight gradient out of images G', X'; image D of the next tile, epilogue of this one
         {
@@ -3293,20 +3319,20 @@ __global__ __launch_bounds__(256) void dwgrad64bf_kernel(DWArgs a) {
             // epilogue of accumulator registers 2 i, 2 i + 1 of the data gradient (two time steps of the lane's channel); every second
             // call completes a quad and stores it
             auto epi2 = [&](int i) {
-#pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    const int r = 2 * i + e;
-                    float v = dacc[r];
-                    const float qv = e1q[r >> 2][r & 3];
-                    if (EPI == EPI_RELUMASK) {
-                        v = (fmaf(qv, kea, keb) > 0.f) ? v : 0.f;
-                        s1 += v; s2 = fmaf(v, qv, s2);
-                        asm volatile("" : "+v"(s1), "+v"(s2));
-                    } else {
-                        v += qv;
-                    }
-                    dacc[r] = v;
+                const int r0 = 2 * i, r1 = 2 * i + 1;
+                float v0 = dacc[r0], v1 = dacc[r1];
+                const float q0_ = e1q[r0 >> 2][r0 & 3], q1_ = e1q[r1 >> 2][r1 & 3];
+                if (EPI == EPI_RELUMASK) {
+                    // both compares first, both selects after: a select right behind its compare costs two wait states
+                    const bool k0 = fmaf(q0_, kea, keb) > 0.f, k1 = fmaf(q1_, kea, keb) > 0.f;
+                    v0 = k0 ? v0 : 0.f; v1 = k1 ? v1 : 0.f;
+                    s1 += v0; s2 = fmaf(v0, q0_, s2);
+                    s1 += v1; s2 = fmaf(v1, q1_, s2);
+                    asm volatile("" : "+v"(s1), "+v"(s2));
+                } else {
+                    v0 += q0_; v1 += q1_;
                 }
+                dacc[r0] = v0; dacc[r1] = v1;
                 if (i & 1) {
                     const int q4 = i >> 1;
                     buf_store4(sye, f32x4{dacc[4 * q4], dacc[4 * q4 + 1], dacc[4 * q4 + 2], dacc[4 * q4 + 3]}, eoff + 32u * q4, 0u);
@@ -3332,7 +3358,7 @@ __global__ __launch_bounds__(256) void dwgrad64bf_kernel(DWArgs a) {
                 else {
                     // 48 free slices: image D of the next tile in every second one of the first 24, the epilogue quads in the last 24
                     const int v = kb * 12 + (mm - 6);             // 0..47
-                    if (v < 2 * NSB) { if ((v & 1) == 0) sideB(v >> 1); }
+                    if (v < 2 * NSB) { if ((v & 1) == 0) sideB(v >> 1); else refillB(v); }
                     else if (v >= 24 && ((v - 24) % 3) == 0) epi2((v - 24) / 3);
                 }
                 if (mm == 12 && kb + 1 < 4) read_kb(kb + 1, set ^ 1);
@@ -3344,7 +3370,7 @@ __global__ __launch_bounds__(256) void dwgrad64bf_kernel(DWArgs a) {
         lds_barrier();          // image D of the next tile is complete; images G', X' of this tile are free
         STAMP(ts4);
 #ifdef WM_STAMP
-        tm[0] += ts1 - ts0; tm[1] += ts2 - ts1; tm[2] += ts3 - ts2; tm[3] += ts4 - ts3;
+        tm[0] += ts1 - ts0; tm[1] += ts2 - ts1; tm[2] += ts3 - ts2; tm[3] += ts4 - ts3; tm[4] += ts1b - ts1;
 #endif
         tile += tstep;
         buf ^= 1;

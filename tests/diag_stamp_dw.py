@@ -29,8 +29,11 @@ def run(name, xpro, epi):
     ms = e0.elapsed_time(e1)
     ntile = B * (T // 64) / 256
     d = buf.view(256, 4, 6).double().mean(dim=(0, 1)) / ntile
-    names = ["phase A (dgrad)", "barrier 1", "phase B (wgrad)", "barrier 2"]
+    names = ["phase A (dgrad)", "barrier 1", "phase B (wgrad)", "barrier 2", "(of barrier 1: LDS drain)"]
     print(f"{name}: B={B} {ms:.3f} ms, per 64-step tile: " + "  ".join(f"{n} {v:6.0f}" for n, v in zip(names, d)) +
           f"  total {float(d[:4].sum()):6.0f} ticks = {ms*1e3/ntile:.2f} us")
+    pw = buf.view(256, 4, 6).double().mean(dim=0) / ntile          # per wave
+    for w in range(4):
+        print(f"    wave {w}: " + "  ".join(f"{n} {float(v):6.0f}" for n, v in zip(names, pw[w])))
 run("conv2 pair (bnrelu / relumask+stats)", 1, 1)
 run("conv1 pair (none / add)", 0, 2)
