@@ -66,43 +66,49 @@ __global__ void bn_eval_kernel(const float* gamma, const float* beta, const floa
 }
 
 // out = relu(x + y*scale[c] + shift[c]);  grid (rows = B*64), float4 over T
-// MASK: also record sign(out) as one bit per element -- the only thing the backward needs from `out`.  Layout
-// mask[row][iteration][wave][e] = 64-bit ballot over the wave's lanes of (element e of the lane's float4 > 0): the backward
-// kernel walks the row with the same thread -> element map, so every lane finds its four bits at its own lane index.
+// MASK: also record sign(out) as one bit per element -- the only thing the backward needs from `out`.  Layout: natural bit
+// order, mask[row][t / 32] bit (t % 32), ceil(T / 32) dwords per (clip, channel) row -- any consumer finds the bits of a run of
+// time steps of one row in one dword (the fused convolution-backward kernels apply the mask while they load the gradient, in
+// their own thread -> element maps).  The lane's four bits are merged with its seven neighbours' by three lane exchanges.
 template <bool MASK>
 __global__ __launch_bounds__(256) void bn_add_relu_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                           const float* __restrict__ scale, const float* __restrict__ shift,
-                                                          float* __restrict__ out, unsigned long long* __restrict__ mask, int T4) {
+                                                          float* __restrict__ out, unsigned* __restrict__ mask, int T4) {
     const int row = blockIdx.x, c = row & 63;
     const float sc = scale[c], sh = shift[c];
     const float4* xr = reinterpret_cast<const float4*>(x) + (size_t)row * T4;
     const float4* yr = reinterpret_cast<const float4*>(y) + (size_t)row * T4;
     float4* orow = reinterpret_cast<float4*>(out) + (size_t)row * T4;
-    const int nit = (T4 + 255) >> 8, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    unsigned long long* mrow = MASK ? mask + ((size_t)row * nit * 4 + wave) * 4 : nullptr;
-    for (int i = threadIdx.x, it = 0; i < T4; i += 256, ++it) {
-        const float4 a = xr[i], b = yr[i];
-        float4 o;
-        o.x = fmaxf(a.x + fmaf(b.x, sc, sh), 0.f);
-        o.y = fmaxf(a.y + fmaf(b.y, sc, sh), 0.f);
-        o.z = fmaxf(a.z + fmaf(b.z, sc, sh), 0.f);
-        o.w = fmaxf(a.w + fmaf(b.w, sc, sh), 0.f);
-        orow[i] = o;
+    const int lane = threadIdx.x & 63, nw = (T4 + 7) >> 3;
+    unsigned* mrow = MASK ? mask + (size_t)row * nw : nullptr;
+    const int nit = (T4 + 255) >> 8;
+    for (int it = 0; it < nit; ++it) {              // every thread runs every iteration: the lane exchanges need all 64 lanes
+        const int i = it * 256 + threadIdx.x;
+        const bool ok = i < T4;
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok) {
+            const float4 a = xr[i], b = yr[i];
+            o.x = fmaxf(a.x + fmaf(b.x, sc, sh), 0.f);
+            o.y = fmaxf(a.y + fmaf(b.y, sc, sh), 0.f);
+            o.z = fmaxf(a.z + fmaf(b.z, sc, sh), 0.f);
+            o.w = fmaxf(a.w + fmaf(b.w, sc, sh), 0.f);
+            orow[i] = o;
+        }
         if (MASK) {
-            const unsigned long long m0 = __ballot(o.x > 0.f), m1 = __ballot(o.y > 0.f), m2 = __ballot(o.z > 0.f), m3 = __ballot(o.w > 0.f);
-            if (lane == 0) {
-                unsigned long long* m = mrow + (size_t)it * 16;
-                m[0] = m0; m[1] = m1; m[2] = m2; m[3] = m3;
-            }
+            unsigned m = ((o.x > 0.f) ? 1u : 0u) | ((o.y > 0.f) ? 2u : 0u) | ((o.z > 0.f) ? 4u : 0u) | ((o.w > 0.f) ? 8u : 0u);
+            m <<= 4 * (lane & 7);
+            m |= __shfl_xor(m, 1); m |= __shfl_xor(m, 2); m |= __shfl_xor(m, 4);
+            if ((lane & 7) == 0 && ok) mrow[i >> 3] = m;
         }
     }
 }
 
 // dz = g * (out > 0);  partial[b][0][c] = sum dz, partial[b][1][c] = sum dz*y   (row = b*64+c).  MASK: the sign bits written by
-// bn_add_relu_kernel<true> stand in for `out` (a 16.4 MB frame pass per clip less)
-template <bool MASK>
+// bn_add_relu_kernel<true> stand in for `out` (a 16.4 MB frame pass per clip less).  WRITE = false: the sums only -- the fused
+// convolution-backward kernels re-apply the mask to g while loading it, so dz is never materialised (another frame pass less).
+template <bool MASK, bool WRITE>
 __global__ __launch_bounds__(256) void relu_bwd_reduce_kernel(const float* __restrict__ g, const float* __restrict__ out,
-                                                              const unsigned long long* __restrict__ mask,
+                                                              const unsigned* __restrict__ mask,
                                                               const float* __restrict__ y, float* __restrict__ dz,
                                                               float* __restrict__ partial, int T4) {
     __shared__ float scratch[8];
@@ -110,16 +116,15 @@ __global__ __launch_bounds__(256) void relu_bwd_reduce_kernel(const float* __res
     const float4* gr = reinterpret_cast<const float4*>(g) + (size_t)row * T4;
     const float4* orow = MASK ? nullptr : reinterpret_cast<const float4*>(out) + (size_t)row * T4;
     const float4* yr = reinterpret_cast<const float4*>(y) + (size_t)row * T4;
-    float4* dr = reinterpret_cast<float4*>(dz) + (size_t)row * T4;
-    const int nit = (T4 + 255) >> 8, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const unsigned long long* mrow = MASK ? mask + ((size_t)row * nit * 4 + wave) * 4 : nullptr;
+    float4* dr = WRITE ? reinterpret_cast<float4*>(dz) + (size_t)row * T4 : nullptr;
+    const unsigned* mrow = MASK ? mask + (size_t)row * ((T4 + 7) >> 3) : nullptr;
     float s1 = 0.f, s2 = 0.f;
-    for (int i = threadIdx.x, it = 0; i < T4; i += 256, ++it) {
+    for (int i = threadIdx.x; i < T4; i += 256) {
         const float4 gg = gr[i], yy = yr[i];
         bool p0, p1, p2, p3;
         if (MASK) {
-            const unsigned long long* m = mrow + (size_t)it * 16;
-            p0 = (m[0] >> lane) & 1; p1 = (m[1] >> lane) & 1; p2 = (m[2] >> lane) & 1; p3 = (m[3] >> lane) & 1;
+            const unsigned m = mrow[i >> 3] >> (4 * (i & 7));
+            p0 = m & 1u; p1 = m & 2u; p2 = m & 4u; p3 = m & 8u;
         } else {
             const float4 oo = orow[i];
             p0 = oo.x > 0.f; p1 = oo.y > 0.f; p2 = oo.z > 0.f; p3 = oo.w > 0.f;
@@ -129,7 +134,7 @@ __global__ __launch_bounds__(256) void relu_bwd_reduce_kernel(const float* __res
         d.y = p1 ? gg.y : 0.f;
         d.z = p2 ? gg.z : 0.f;
         d.w = p3 ? gg.w : 0.f;
-        dr[i] = d;
+        if (WRITE) dr[i] = d;
         s1 += (d.x + d.y) + (d.z + d.w);
         s2 += fmaf(d.x, yy.x, d.y * yy.y) + fmaf(d.z, yy.z, d.w * yy.w);
     }
@@ -195,18 +200,17 @@ int wm_bn_eval_scale_shift(const float* gamma, const float* beta, const float* r
 int wm_bn_add_relu(const float* x, const float* y2, const float* scale, const float* shift, float* out, int B, int T,
                    hipStream_t stream) {
     if (T & 3) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(bn_add_relu_kernel<false>, dim3(B * 64), dim3(256), 0, stream, x, y2, scale, shift, out, (unsigned long long*)nullptr, T / 4);
+    hipLaunchKernelGGL(bn_add_relu_kernel<false>, dim3(B * 64), dim3(256), 0, stream, x, y2, scale, shift, out, (unsigned*)nullptr, T / 4);
     WM_CHECK_LAUNCH();
     return 0;
 }
 
-// The same tail + the sign bits of `out` for wm_relu_bwd_reduce_mask: mask holds 16 * ceil(T / 1024) 64-bit words per
-// (clip, channel) row.
+// The same tail + the sign bits of `out`: mask holds ceil(T / 32) dwords per (clip, channel) row, bit (t % 32) of dword t / 32.
 int wm_bn_add_relu_mask(const float* x, const float* y2, const float* scale, const float* shift, float* out, void* mask, int B, int T,
                         hipStream_t stream) {
     if ((T & 3) || !mask) return (int)hipErrorInvalidValue;
     hipLaunchKernelGGL(bn_add_relu_kernel<true>, dim3(B * 64), dim3(256), 0, stream, x, y2, scale, shift, out,
-                       reinterpret_cast<unsigned long long*>(mask), T / 4);
+                       reinterpret_cast<unsigned*>(mask), T / 4);
     WM_CHECK_LAUNCH();
     return 0;
 }
@@ -215,16 +219,21 @@ int wm_bn_add_relu_mask(const float* x, const float* y2, const float* scale, con
 int wm_relu_bwd_reduce(const float* g, const float* out, const float* y2, float* dz, float* partial, int B, int T,
                        hipStream_t stream) {
     if (T & 3) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(relu_bwd_reduce_kernel<false>, dim3(B * 64), dim3(256), 0, stream, g, out, (const unsigned long long*)nullptr, y2, dz, partial, T / 4);
+    hipLaunchKernelGGL((relu_bwd_reduce_kernel<false, true>), dim3(B * 64), dim3(256), 0, stream, g, out, (const unsigned*)nullptr, y2, dz, partial, T / 4);
     WM_CHECK_LAUNCH();
     return 0;
 }
 
+// The same from the sign bits; dz == NULL: only the two sums (the consumer masks g itself: wm_dwgrad64_bf's gmask).
 int wm_relu_bwd_reduce_mask(const float* g, const void* mask, const float* y2, float* dz, float* partial, int B, int T,
                             hipStream_t stream) {
     if ((T & 3) || !mask) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(relu_bwd_reduce_kernel<true>, dim3(B * 64), dim3(256), 0, stream, g, (const float*)nullptr,
-                       reinterpret_cast<const unsigned long long*>(mask), y2, dz, partial, T / 4);
+    if (dz)
+        hipLaunchKernelGGL((relu_bwd_reduce_kernel<true, true>), dim3(B * 64), dim3(256), 0, stream, g, (const float*)nullptr,
+                           reinterpret_cast<const unsigned*>(mask), y2, dz, partial, T / 4);
+    else
+        hipLaunchKernelGGL((relu_bwd_reduce_kernel<true, false>), dim3(B * 64), dim3(256), 0, stream, g, (const float*)nullptr,
+                           reinterpret_cast<const unsigned*>(mask), y2, (float*)nullptr, partial, T / 4);
     WM_CHECK_LAUNCH();
     return 0;
 }

@@ -2933,9 +2933,11 @@ struct DWArgs {
     float* stats;                                       // [grid][2][64] (RELUMASK) or null
     float* partial;                                     // weight-gradient slabs [grid][3*4096 + 64]
     int B, T;
+    const unsigned* gmask;                              // GM: sign bits of the ReLU the incoming gradient passes (bit t % 32 of dword
+                                                        // [row][t / 32]): applied to g (conv2 pair) / to e1 (conv1 pair) on load
 };
 
-template <int EPI, int XPRO>
+template <int EPI, int XPRO, bool GM>
 __global__ __launch_bounds__(256) void dwgrad64bf_kernel(DWArgs a) {
     static_assert((EPI == EPI_RELUMASK && XPRO == PRO_BNRELU) || (EPI == EPI_ADD && XPRO == PRO_NONE), "conv2 pair or conv1 pair");
     constexpr int KW = 3, NT = 64, NP = 3, ROWS = NT + 2, PITCH = 72, PG = 72, PX = 88, XO = 8;
@@ -2975,9 +2977,13 @@ __global__ __launch_bounds__(256) void dwgrad64bf_kernel(DWArgs a) {
     float4 gz_;                                                // the rebuilt gradient of the (unit, channel) being split
     unsigned gp_[2][2][6];                                     // its bf16 pieces [unit][channel][piece * 2 + time pair] (phase A -> phase B)
     float hg = 0.f, hy = 0.f, hxv = 0.f;
-    wm_srd_t dsg = make_srd(a.g, 0), dsy = dsg, dsx = dsg;
+    wm_srd_t dsg = make_srd(a.g, 0), dsy = dsg, dsx = dsg, dsm = dsg;
     unsigned voff = 0, hoff = 0;
     bool okh = true;
+    constexpr bool GMG = GM && EPI == EPI_RELUMASK;      // the mask belongs to the gradient operand g (else, with GM, to e1)
+    unsigned mk_[2][2] = {{0u, 0u}, {0u, 0u}}, hmk = 0u; // mask dwords of (unit, channel) / of the halo step, as loaded
+    unsigned voffm = 0, hoffm = 0, hsh = 0, hsh_cur = 0;
+    const unsigned nwm = (unsigned)T >> 5;               // mask dwords per row (T % 64 == 0)
     auto set_tile = [&](int tile) {
         const int b = tile / tilesPerClip, t0 = (tile - b * tilesPerClip) * NT;
         const size_t clip = (size_t)b * 64 * T, bytes = (size_t)64 * T * sizeof(float);
@@ -2988,6 +2994,13 @@ __global__ __launch_bounds__(256) void dwgrad64bf_kernel(DWArgs a) {
         const int th = hh ? t0 + NT : t0 - 1;
         hoff = (unsigned)(hc * T + min(max(th, 0), T - 1)) * 4u;
         okh = th >= 0 && th < T;
+        if (GMG) {
+            dsm = make_srd(reinterpret_cast<const float*>(a.gmask) + (size_t)b * 64 * nwm, (size_t)64 * nwm * sizeof(unsigned));
+            voffm = ((unsigned)c0 * nwm + ((unsigned)t0 >> 5)) * 4u;
+            const int thc = min(max(th, 0), T - 1);
+            hoffm = ((unsigned)hc * nwm + ((unsigned)thc >> 5)) * 4u;
+            hsh = (unsigned)thc & 31u;
+        }
     };
     const unsigned rowT = (unsigned)T * 4u;
     auto load_g = [&](int u) {
@@ -3013,6 +3026,12 @@ __global__ __launch_bounds__(256) void dwgrad64bf_kernel(DWArgs a) {
         if (m == 44) rb_[1] = __builtin_bit_cast(float4, buf_load4(dsg, voff + 128u, rowT));
         if (m == 50) ya_[1] = __builtin_bit_cast(float4, buf_load4(dsy, voff + 128u, 0u));
         if (m == 56) yb_[1] = __builtin_bit_cast(float4, buf_load4(dsy, voff + 128u, rowT));
+        if (GMG) {
+            if (m == 16) mk_[0][0] = __builtin_bit_cast(unsigned, buf_load(dsm, voffm, 0u));
+            if (m == 22) mk_[0][1] = __builtin_bit_cast(unsigned, buf_load(dsm, voffm, nwm * 4u));
+            if (m == 40) mk_[1][0] = __builtin_bit_cast(unsigned, buf_load(dsm, voffm + 4u, 0u));
+            if (m == 46) mk_[1][1] = __builtin_bit_cast(unsigned, buf_load(dsm, voffm + 4u, nwm * 4u));
+        }
     };
     auto refillB = [&](int v) {                     // phase-B free slice v
         if (v == 1) xa_[0] = __builtin_bit_cast(float4, buf_load4(dsx, voff, 0u));
@@ -3020,7 +3039,14 @@ __global__ __launch_bounds__(256) void dwgrad64bf_kernel(DWArgs a) {
         if (v == 13) xa_[1] = __builtin_bit_cast(float4, buf_load4(dsx, voff + 128u, 0u));
         if (v == 19) xb_[1] = __builtin_bit_cast(float4, buf_load4(dsx, voff + 128u, rowT));
     };
-    auto load_ghalo = [&]() { hg = buf_load(dsg, hoff, 0u); hy = buf_load(dsy, hoff, 0u); };
+    auto load_ghalo = [&]() {
+        hg = buf_load(dsg, hoff, 0u); hy = buf_load(dsy, hoff, 0u);
+        if (GMG) hmk = __builtin_bit_cast(unsigned, buf_load(dsm, hoffm, 0u));
+    };
+    auto load_gmask = [&](int u) {
+        mk_[u][0] = __builtin_bit_cast(unsigned, buf_load(dsm, voffm + 4u * u, 0u));
+        mk_[u][1] = __builtin_bit_cast(unsigned, buf_load(dsm, voffm + 4u * u, nwm * 4u));
+    };
     auto load_xhalo = [&]() { hxv = buf_load(dsx, hoff, 0u); };
 
     const int tstep = gridDim.x;
@@ -3028,6 +3054,8 @@ __global__ __launch_bounds__(256) void dwgrad64bf_kernel(DWArgs a) {
     set_tile(tile);
     bool okh_cur = okh;
     load_g(0); load_g(1); load_x(0); load_x(1); load_ghalo(); load_xhalo();
+    if (GMG) { load_gmask(0); load_gmask(1); }
+    hsh_cur = hsh;
     if (tid < 64) {
         Cs[tid] = a.ga[tid];
         Cs[64 + tid] = a.gb[tid];
@@ -3092,8 +3120,12 @@ __global__ __launch_bounds__(256) void dwgrad64bf_kernel(DWArgs a) {
     auto g_build = [&](int u, int j, int e) {
         const float4 dz = j ? rb_[u] : ra_[u], yy = j ? yb_[u] : ya_[u];
         float4& gz = gz_;
-        const float d = (e == 0) ? dz.x : (e == 1) ? dz.y : (e == 2) ? dz.z : dz.w;
+        float d = (e == 0) ? dz.x : (e == 1) ? dz.y : (e == 2) ? dz.z : dz.w;
         const float yv = (e == 0) ? yy.x : (e == 1) ? yy.y : (e == 2) ? yy.z : yy.w;
+        if (GMG) {                          // dz = g_out where the block output was positive: its bit, sign-extended, ANDed in
+            if (e == 0) mk_[u][j] >>= 4 * q0;
+            d = __uint_as_float(__float_as_uint(d) & (unsigned)__builtin_amdgcn_sbfe((int)mk_[u][j], e, 1));
+        }
         float v = pro_apply<PRO_BNBWD>(d, yv, kga[j], kgb[j], kgc[j], kgl[j]);
         bsum[j] = fmaf(bflag, v, bsum[j]);
         asm volatile("" : "+v"(v), "+v"(bsum[j]));
@@ -3140,7 +3172,9 @@ __global__ __launch_bounds__(256) void dwgrad64bf_kernel(DWArgs a) {
         }
     };
     auto hg_pick = [&]() {
-        const float v = pro_apply<PRO_BNBWD>(hg, hy, hga, hgb, hgc, hgl);
+        float hgm = hg;
+        if (GMG) hgm = __uint_as_float(__float_as_uint(hg) & (unsigned)__builtin_amdgcn_sbfe((int)(hmk >> hsh_cur), 0, 1));
+        const float v = pro_apply<PRO_BNBWD>(hgm, hy, hga, hgb, hgc, hgl);
         va = okh_cur ? v : 0.f; vb = 0.f;
         asm volatile("" : "+v"(va), "+v"(vb));
     };
@@ -3203,9 +3237,10 @@ __global__ __launch_bounds__(256) void dwgrad64bf_kernel(DWArgs a) {
         const bool okh_n = okh;
 #pragma unroll
         for (int v = 0; v < NSA; ++v) { sideA(v, Gb0, Xb0); refillA(v); }
+        const unsigned hsh_n = hsh;
 #pragma unroll
         for (int v = 0; v < 2 * NSB; ++v) { if ((v & 1) == 0) sideB(v >> 1); else refillB(v); }
-        okh_cur = okh_n;
+        okh_cur = okh_n; hsh_cur = hsh_n;
     }
     __syncthreads();
 
@@ -3220,6 +3255,7 @@ __global__ __launch_bounds__(256) void dwgrad64bf_kernel(DWArgs a) {
     // sums are one register each instead of sixteen.
     float s1 = 0.f, s2 = 0.f;
     f32x4 e1q[4];
+    unsigned emk = 0u;
     const float kea = (EPI == EPI_RELUMASK) ? Cs[384 + 32 * mt + l31] : 0.f, keb = (EPI == EPI_RELUMASK) ? Cs[448 + 32 * mt + l31] : 0.f;
     int buf = 0;
 #ifdef WM_STAMP
@@ -3232,6 +3268,7 @@ __global__ __launch_bounds__(256) void dwgrad64bf_kernel(DWArgs a) {
         bflag = (tile + tstep < ntiles) ? 1.f : 0.f;
         set_tile(min(tile + 2 * tstep, ntiles - 1));       // what the refills inside the slices fetch
         const bool okh_n = okh;
+        const unsigned hsh_n = hsh;
         const unsigned short* Gc = Gb0 + buf * GIMG;
         const unsigned short* Xc = Xb0 + buf * XIMG;
         unsigned short* Gn = Gb0 + (buf ^ 1) * GIMG;
@@ -3241,6 +3278,11 @@ __global__ __launch_bounds__(256) void dwgrad64bf_kernel(DWArgs a) {
         const wm_srd_t sye = make_srd(a.y + slab, (size_t)32 * T * sizeof(float));
         const wm_srd_t se1 = make_srd(a.e1 + slab, (size_t)32 * T * sizeof(float));
         const unsigned eoff = (unsigned)(l31 * T + t0 + 32 * nh + 4 * half) * 4u;
+        // GM, conv1 pair: e1 is the gradient that reaches the block output; its ReLU bits: dword t0 / 32 + nh of the lane's row
+        constexpr bool GME = GM && EPI == EPI_ADD;
+        const wm_srd_t sme = GME ? make_srd(reinterpret_cast<const float*>(a.gmask) + ((size_t)b * 64 + 32 * mt) * nwm,
+                                            (size_t)32 * nwm * sizeof(unsigned)) : se1;
+        const unsigned emoff = ((unsigned)l31 * nwm + ((unsigned)t0 >> 5) + (unsigned)nh) * 4u;
 
         STAMP(ts0);
         // ---------------- phase A: data gradient out of image D
@@ -3272,6 +3314,7 @@ __global__ __launch_bounds__(256) void dwgrad64bf_kernel(DWArgs a) {
                     const int m = s * 6 + j;                         // 0..71
                     if (m < NSA) { sideA(m, Gn, Xn); refillA(m); }
                     else if (((m - NSA) & 1) == 0) e1q[(m - NSA) >> 1] = buf_load4(se1, eoff + 32u * ((m - NSA) >> 1), 0u);
+                    else if (GME && m == NSA + 1) emk = __builtin_bit_cast(unsigned, buf_load(sme, emoff, 0u));
                     FENCE;
                 }
             }
@@ -3329,6 +3372,11 @@ __global__ __launch_bounds__(256) void dwgrad64bf_kernel(DWArgs a) {
                     s1 += v0; s2 = fmaf(v0, q0_, s2);
                     s1 += v1; s2 = fmaf(v1, q1_, s2);
                     asm volatile("" : "+v"(s1), "+v"(s2));
+                } else if (GM) {
+                    // bits 8 q + 4 half + e of the row's dword: shifted by 4 half once (first call), then constant field positions
+                    if (i == 0) emk >>= 4 * half;
+                    v0 += __uint_as_float(__float_as_uint(q0_) & (unsigned)__builtin_amdgcn_sbfe((int)emk, 8 * (r0 >> 2) + (r0 & 3), 1));
+                    v1 += __uint_as_float(__float_as_uint(q1_) & (unsigned)__builtin_amdgcn_sbfe((int)emk, 8 * (r1 >> 2) + (r1 & 3), 1));
                 } else {
                     v0 += q0_; v1 += q1_;
                 }
@@ -3364,7 +3412,7 @@ __global__ __launch_bounds__(256) void dwgrad64bf_kernel(DWArgs a) {
                 if (mm == 12 && kb + 1 < 4) read_kb(kb + 1, set ^ 1);
                 FENCE;
             }
-            okh_cur = okh_n;
+            okh_cur = okh_n; hsh_cur = hsh_n;
         }
         STAMP(ts3);
         lds_barrier();          // image D of the next tile is complete; images G', X' of this tile are free
@@ -3409,11 +3457,11 @@ __global__ __launch_bounds__(256) void dwgrad64bf_kernel(DWArgs a) {
     }
 }
 
-template <int EPI, int XPRO>
+template <int EPI, int XPRO, bool GM>
 int launch_dwgrad64bf(const DWArgs& a, int* grid_out, hipStream_t stream) {
     constexpr size_t lds = (size_t)(3 * 66 * 72 + 2 * 3 * 64 * 72 + 2 * 3 * 64 * 88) * 2 + 8 * 64 * sizeof(float);
     static wm::DevOnce attr_done;
-    auto kern = dwgrad64bf_kernel<EPI, XPRO>;
+    auto kern = dwgrad64bf_kernel<EPI, XPRO, GM>;
     if (!wm::dev_done(attr_done)) {
         WM_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         wm::dev_mark(attr_done);
@@ -3598,13 +3646,15 @@ int wm_wgrad64_bf(const float* g, const float* g2, const float* ga, const float*
 int wm_dwgrad64_bf(const float* g, const float* g2, const float* ga, const float* gb, const float* gc, const void* wpb,
                    const float* x, const float* xa, const float* xb, const float* e1, const float* ea, const float* eb,
                    float* y, float* stats, float* partial, float* dw, float* dbias, int B, int T, int xpro, int epi, int accumulate,
-                   hipStream_t stream) {
+                   const void* gmask, hipStream_t stream) {
     if (B <= 0 || T <= 0 || (T & 63)) return (int)hipErrorInvalidValue;
     if (!g || !g2 || !ga || !gb || !gc || !wpb || !x || !e1 || !y || !partial || !dw) return (int)hipErrorInvalidValue;
-    DWArgs a{g, g2, ga, gb, gc, wpb, x, xa, xb, e1, ea, eb, y, stats, partial, B, T};
+    DWArgs a{g, g2, ga, gb, gc, wpb, x, xa, xb, e1, ea, eb, y, stats, partial, B, T, reinterpret_cast<const unsigned*>(gmask)};
     int grid = 0, rc = (int)hipErrorInvalidValue;
-    if (epi == EPI_RELUMASK && xpro == PRO_BNRELU && stats && xa && xb && ea && eb) rc = launch_dwgrad64bf<EPI_RELUMASK, PRO_BNRELU>(a, &grid, stream);
-    else if (epi == EPI_ADD && xpro == PRO_NONE && !stats) rc = launch_dwgrad64bf<EPI_ADD, PRO_NONE>(a, &grid, stream);
+    if (epi == EPI_RELUMASK && xpro == PRO_BNRELU && stats && xa && xb && ea && eb)
+        rc = gmask ? launch_dwgrad64bf<EPI_RELUMASK, PRO_BNRELU, true>(a, &grid, stream) : launch_dwgrad64bf<EPI_RELUMASK, PRO_BNRELU, false>(a, &grid, stream);
+    else if (epi == EPI_ADD && xpro == PRO_NONE && !stats)
+        rc = gmask ? launch_dwgrad64bf<EPI_ADD, PRO_NONE, true>(a, &grid, stream) : launch_dwgrad64bf<EPI_ADD, PRO_NONE, false>(a, &grid, stream);
     if (rc) return rc;
     const int n = 3 * 4096 + 64;
     hipLaunchKernelGGL(wgrad64_reduce_kernel, dim3((n + 63) / 64), dim3(256), 0, stream, (const float*)partial, grid, 3, 0, dw,

@@ -147,7 +147,8 @@ def _on_side(inputs, fn, defer=True):
 import os as _os
 _CONV = {"bf16x6": _os.environ.get("WM_CONV_BF16X6", "1") == "1", "schedule": 2,
          "one_launch_eval": _os.environ.get("WM_RESBLOCK_ONE_LAUNCH", "1") == "1",
-         "fused_bwd": _os.environ.get("WM_FUSED_BWD", "1") == "1"}
+         "fused_bwd": _os.environ.get("WM_FUSED_BWD", "1") == "1",
+         "mask_on_load": _os.environ.get("WM_MASK_ON_LOAD", "1") == "1"}
 
 
 def set_conv_bf_schedule(schedule: int):
@@ -168,6 +169,12 @@ def set_fused_backward(on: bool):
     """ResBlock backward: data gradient + weight gradient of each convolution in ONE launch (wm_dwgrad64_bf, default) or as two
     (wm_conv64_bf + wm_wgrad64_bf).  WM_FUSED_BWD=0/1 in the environment sets the default."""
     _CONV["fused_bwd"] = bool(on)
+
+
+def set_mask_on_load(on: bool):
+    """fused ResBlock backward: 1 (default) the masked gradient dz2 = g * (out > 0) is never written -- the reduction pass forms
+    only the BatchNorm sums and wm_dwgrad64_bf masks g on load; 0 it is materialised first.  WM_MASK_ON_LOAD=0/1 sets the default."""
+    _CONV["mask_on_load"] = bool(on)
 
 
 def set_resblock_one_launch(on: bool):
@@ -252,7 +259,7 @@ class ResBlockFn(GradAwareFunction):
             mu1.copy_(rm1); is1.copy_(torch.rsqrt(rv1 + BN_EPS)); mu2.copy_(rm2); is2.copy_(torch.rsqrt(rv2 + BN_EPS))
         if wants_grad(ctx):
             # the backward needs only the SIGN of `out`: one bit per element, written beside it (a frame pass less in backward)
-            mask = torch.empty(B * 64 * 16 * ((T + 1023) // 1024), dtype=torch.int64, device=dev)
+            mask = torch.empty(B * 64 * ((T + 31) // 32), dtype=torch.int32, device=dev)
             lib.wm_bn_add_relu_mask(_p(x), _p(y2), _p(sc2), _p(sh2), _p(out), _p(mask), B, T, st)
         else:
             mask = None
@@ -271,8 +278,13 @@ class ResBlockFn(GradAwareFunction):
         dev, st = x.device, _stream()
         ev = 0 if ctx.training else 1
         n = float(B * T)
-        dz2 = torch.empty_like(x)
         part = _f32(max(B, 1) * 128, device=dev)
+        gw1, gb1, gw2, gb2 = ctx.gdst
+        side = all(g is not None for g in ctx.gdst)
+        fused = _CONV["bf16x6"] and _CONV["fused_bwd"] and not side and T % 64 == 0
+        # dz2 = g_out * (out > 0).  Fused path: never written -- the reduction pass only forms the two BatchNorm sums, and the two
+        # convolution-backward launches mask g_out with the same bits while they load it (wm_dwgrad64_bf's gmask)
+        dz2 = None if (fused and _CONV["mask_on_load"]) else torch.empty_like(x)
         lib.wm_relu_bwd_reduce_mask(_p(g_out), _p(mask), _p(y2), _p(dz2), _p(part), B, T, st)
         k2 = _f32(4, 64, device=dev)          # A, B (hi), B (lo), C  -- B is handed over as hi + lo words
         dg2, dbe2 = _f32(64, device=dev), _f32(64, device=dev)
@@ -280,20 +292,19 @@ class ResBlockFn(GradAwareFunction):
         # conv2: data gradient (+ ReLU mask + BN1-backward reductions in the epilogue) and weight gradient
         dz1 = torch.empty_like(x)
         stats = _f32(NCU * 128, device=dev)
-        gw1, gb1, gw2, gb2 = ctx.gdst
-        side = all(g is not None for g in ctx.gdst)
-        if _CONV["bf16x6"] and _CONV["fused_bwd"] and not side and T % 64 == 0:
+        if fused:
             # data gradient AND weight gradient of each convolution in one launch: the gradient frames are read once
+            gsrc, gm = (g_out, mask) if dz2 is None else (dz2, None)
             dw2, db2, dw1, db1 = torch.empty_like(w2), _f32(64, device=dev), torch.empty_like(w1), _f32(64, device=dev)
             wpart = _f32(NCU * (3 * 4096 + 64), device=dev)
-            lib.wm_dwgrad64_bf(_p(dz2), _p(y2), _p(k2[0]), _p(k2[1]), _p(k2[3]), _p(pack_w64_bf(w2, 1)), _p(y1), _p(sc1), _p(sh1),
-                               _p(y1), _p(sc1), _p(sh1), _p(dz1), _p(stats), _p(wpart), _p(dw2), _p(db2), B, T, 1, 1, 0, st)
+            lib.wm_dwgrad64_bf(_p(gsrc), _p(y2), _p(k2[0]), _p(k2[1]), _p(k2[3]), _p(pack_w64_bf(w2, 1)), _p(y1), _p(sc1), _p(sh1),
+                               _p(y1), _p(sc1), _p(sh1), _p(dz1), _p(stats), _p(wpart), _p(dw2), _p(db2), B, T, 1, 1, 0, _p(gm), st)
             k1 = _f32(4, 64, device=dev)
             dg1, dbe1 = _f32(64, device=dev), _f32(64, device=dev)
             lib.wm_bn_bwd_finalize(_p(stats), NCU, n, _p(g1), _p(mu1), _p(is1), _p(k1[0]), _p(k1[1]), _p(k1[3]), _p(dg1), _p(dbe1), 0, ev, st)
             dx = torch.empty_like(x)
             lib.wm_dwgrad64_bf(_p(dz1), _p(y1), _p(k1[0]), _p(k1[1]), _p(k1[3]), _p(pack_w64_bf(w1, 1)), _p(x), None, None,
-                               _p(dz2), None, None, _p(dx), None, _p(wpart), _p(dw1), _p(db1), B, T, 0, 2, 0, st)
+                               _p(gsrc), None, None, _p(dx), None, _p(wpart), _p(dw1), _p(db1), B, T, 0, 2, 0, _p(gm), st)
             return dx, dw1, db1, dg1, dbe1, dw2, db2, dg2, dbe2, None, None, None, None, None, None, None
         _conv3(dz2, y2, w2, 1, k2[0], k2[1], k2[3], None, y1, sc1, sh1, dz1, stats, B, T, 3, 1)
 

@@ -81,11 +81,14 @@ int wm_resblock_eval_bf(const float* x, const void* w1pb, const void* w2pb, cons
  *   xpro 1, epi 1: x' = relu(x xa + xb) is the weight gradient's input operand; y = data gradient masked by (e1 ea + eb > 0),
  *                  stats [256][2][64] = (sum y, sum y e1) per workgroup (reduce with wm_bn_bwd_finalize)       [conv2 of a block]
  *   xpro 0, epi 2: x as is; y = data gradient + e1; stats NULL                                                 [conv1 of a block]
+ * gmask (optional): the sign bits wm_bn_add_relu_mask wrote for the block output.  With it the gradient that reaches the block
+ * output is passed as it arrived and masked on load -- as dz in the first form, as e1 in the second -- so the masked copy
+ * dz = g (out > 0) never exists in memory (wm_relu_bwd_reduce_mask with dz = NULL supplies the two BatchNorm sums).
  * dw [out][in][3] / dbias [64] as wm_wgrad64_bf (partial: 256 x (3*4096+64) floats of scratch; accumulate 0 | 1).  T % 64 == 0. */
 int wm_dwgrad64_bf(const float* g, const float* g2, const float* ga, const float* gb, const float* gc, const void* wpb,
                    const float* x, const float* xa, const float* xb, const float* e1, const float* ea, const float* eb,
                    float* y, float* stats, float* partial, float* dw, float* dbias, int B, int T, int xpro, int epi, int accumulate,
-                   wm_stream_t stream);
+                   const void* gmask, wm_stream_t stream);
 
 /* bf16x6 build of the 7-tap ConvTranspose1d(64,64,7,padding=3) (py/main16.py:144): wpb [3][7][64][64] uint16 from
  * wm_pack_w64_bf7 (mode 2 forward | 3 data gradient).  pro 0 x | 2 x + vec[b*64+c]; epi 0 + bias[c] | 3 none. */
@@ -122,9 +125,10 @@ int wm_bn_add_relu(const float* x, const float* y2, const float* scale, const fl
                    wm_stream_t stream);
 int wm_relu_bwd_reduce(const float* g, const float* out, const float* y2, float* dz, float* partial, int B, int T,
                        wm_stream_t stream);
-/* The same pair with the sign of `out` carried as one bit per element (mask: 16 * ceil(T / 1024) 64-bit words per (clip,
- * channel) row, B * 64 rows; an opaque layout shared by the two kernels): the backward then reads g, y2 and 3 % of a frame
- * instead of g, out, y2.  What ResBlock training uses. */
+/* The same pair with the sign of `out` carried as one bit per element: mask = ceil(T / 32) 32-bit words per (clip, channel) row,
+ * B * 64 rows, bit (t % 32) of word t / 32 set where out > 0.  The backward then reads g, y2 and 3 % of a frame instead of g, out,
+ * y2; with dz = NULL it only forms the two sums (the masked gradient is then rebuilt on load by wm_dwgrad64_bf's gmask).  What
+ * ResBlock training uses. */
 int wm_bn_add_relu_mask(const float* x, const float* y2, const float* scale, const float* shift, float* out, void* mask, int B, int T,
                         wm_stream_t stream);
 int wm_relu_bwd_reduce_mask(const float* g, const void* mask, const float* y2, float* dz, float* partial, int B, int T,

@@ -21,7 +21,7 @@ def run(name, xpro, epi):
             vp(y1.data_ptr()), vp(sc.data_ptr()) if xpro else None, vp(sh.data_ptr()) if xpro else None,
             vp(y1.data_ptr()), vp(sc.data_ptr()) if epi == 1 else None, vp(sh.data_ptr()) if epi == 1 else None,
             vp(out.data_ptr()), vp(stats.data_ptr()) if epi == 1 else None, vp(wpart.data_ptr()), vp(dw.data_ptr()), vp(db.data_ptr()),
-            B, T, xpro, epi, 0, None]
+            B, T, xpro, epi, 0, None, None]
     e0, e1 = torch.cuda.Event(True), torch.cuda.Event(True)
     for _ in range(3):
         buf.zero_(); torch.cuda.synchronize(); e0.record(); rc = L.wm_dwgrad64_bf(*args); e1.record(); torch.cuda.synchronize()

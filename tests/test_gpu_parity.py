@@ -335,16 +335,58 @@ def test_relu_mask_kernels_bit_exact(awm, dev, B, T):
     sc, sh = (torch.rand(64, generator=torch.Generator().manual_seed(54)) + 0.5).to(dev), rnd(64, seed=55, scale=0.3).to(dev)
     st = torch.cuda.current_stream().cuda_stream
     out_a, out_b = torch.empty_like(x), torch.empty_like(x)
-    mask = torch.zeros(B * 64 * 16 * ((T + 1023) // 1024), dtype=torch.int64, device=dev)
+    nw = (T + 31) // 32
+    mask = torch.full((B * 64 * nw,), -1, dtype=torch.int32, device=dev)
     lib.wm_bn_add_relu(p(x), p(y2), p(sc), p(sh), p(out_a), B, T, st)
     lib.wm_bn_add_relu_mask(p(x), p(y2), p(sc), p(sh), p(out_b), p(mask), B, T, st)
     assert torch.equal(out_a, out_b)
+    # the documented layout (include/wm_hip.h): bit t % 32 of word t / 32 of row (b, c) is (out > 0); bits past T are zero
+    bits = torch.zeros(B * 64, nw * 32, dtype=torch.int64, device=dev)
+    bits[:, :T] = (out_a > 0).reshape(B * 64, T).long()
+    want = (bits.reshape(B * 64, nw, 32) << torch.arange(32, device=dev)).sum(dim=2)
+    assert torch.equal(mask.reshape(B * 64, nw).long() & 0xFFFFFFFF, want)
     dz_a, dz_b = torch.empty_like(x), torch.empty_like(x)
-    part_a, part_b = torch.zeros(B * 128, device=dev), torch.zeros(B * 128, device=dev)
+    part_a, part_b, part_c = (torch.zeros(B * 128, device=dev) for _ in range(3))
     lib.wm_relu_bwd_reduce(p(g), p(out_a), p(y2), p(dz_a), p(part_a), B, T, st)
     lib.wm_relu_bwd_reduce_mask(p(g), p(mask), p(y2), p(dz_b), p(part_b), B, T, st)
-    assert torch.equal(dz_a, dz_b) and torch.equal(part_a, part_b)
+    lib.wm_relu_bwd_reduce_mask(p(g), p(mask), p(y2), None, p(part_c), B, T, st)          # the sums alone (dz never written)
+    assert torch.equal(dz_a, dz_b) and torch.equal(part_a, part_b) and torch.equal(part_a, part_c)
     assert torch.equal(dz_a, torch.where(out_a > 0, g, torch.zeros_like(g)))
+
+
+@pytest.mark.parametrize("B,T", [(1, 64), (2, 192), (3, 640), (2, 16000)])
+def test_resblock_backward_mask_on_load_is_bit_identical(awm, dev, B, T):
+    """fused ResBlock backward with the ReLU mask applied while the gradient is loaded (default: dz2 = g (out > 0) is never
+    written; wm_relu_bwd_reduce_mask forms only the sums, wm_dwgrad64_bf takes gmask) against the same launches on a
+    materialised dz2: the masked value is the same bits either way, so every gradient must be IDENTICAL."""
+    if not awm.ops.conv_bf16x6():
+        pytest.skip("fused backward is the bf16x6 build")
+    sd = _resblock_state(77 + B)
+    x = rnd(B, 64, T, seed=43).abs() * 0.7
+    g = rnd(B, 64, T, seed=44)
+    res, seen = {}, []
+    orig = awm.lib.wm_dwgrad64_bf
+
+    def spy(*a):
+        seen.append(a[22] is not None)                         # gmask
+        return orig(*a)
+    awm.lib.wm_dwgrad64_bf = spy
+    try:
+        for on in (True, False):
+            awm.ops.set_mask_on_load(on)
+            del seen[:]
+            m = awm.ResBlock(64)
+            m.load_state_dict(sd)
+            m.to(dev).train()
+            xd = x.to(dev).requires_grad_()
+            m(xd).backward(g.to(dev))
+            assert seen == [on, on], seen
+            res[on] = {"dx": xd.grad.clone(), **{k: p.grad.clone() for k, p in m.named_parameters()}}
+    finally:
+        awm.lib.wm_dwgrad64_bf = orig
+        awm.ops.set_mask_on_load(True)
+    for k in res[True]:
+        assert torch.equal(res[True][k], res[False][k]), (k, float((res[True][k] - res[False][k]).abs().max()))
 
 
 # ------------------------------------------------------------------------------------------ convT + embedding
