@@ -23,6 +23,17 @@ using namespace wm;
 
 namespace {
 
+// -DWM_STAMP (diagnostic build, tests/diag_stamp_lstm.py): s_memtime stamps inside a recurrence step, summed over the steps of a
+// clip per segment and written to a buffer of their own.  LSTAMP(var, val) stamps once `val` exists (and holds later uses of it back).
+#ifdef WM_STAMP
+__device__ unsigned long long* g_lstm_stamp = nullptr;
+#define LSTAMP(var, val) unsigned long long var; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var), "+v"(val))
+#define LSTAMP_ACC(i, a, b) tm[i] += (b) - (a)
+#else
+#define LSTAMP(var, val)
+#define LSTAMP_ACC(i, a, b)
+#endif
+
 // Per-step tensors (xp / gates / da) are stored [B][T][256] with the column order  n' = unit*4 + gate  so that the
 // four gates of a hidden unit sit in four adjacent lanes (one DPP quad) of the recurrence kernels and every per-step
 // access of a wave is one contiguous 256-B segment.  gate row of the PyTorch parameters: n = gate*64 + unit.
@@ -111,6 +122,75 @@ __device__ __forceinline__ T2 pk_fma_lanes(T2 w, float v, int k, T2 acc) {
     return acc;
 }
 
+// The same products with the lane reads issued AHEAD of the products that consume them: a v_readlane writes its SGPR late, and a
+// product issued right behind the two reads of its own operand pair stalls on that write (the stamped step showed 610 cycles
+// for 32 reads + 32 products).  N values (lanes k0 .. k0 + N - 1 of v) go into N scalar registers first, behind a scheduling
+// fence; the products then find their operands complete.
+template <int N>
+__device__ __forceinline__ void lanes_to_sgprs(float v, int k0, unsigned long long (&pr)[N / 2]) {
+#pragma unroll
+    for (int i = 0; i < N / 2; ++i) {
+        const unsigned lo = (unsigned)__builtin_amdgcn_readlane(__float_as_int(v), k0 + 2 * i);
+        const unsigned hi = (unsigned)__builtin_amdgcn_readlane(__float_as_int(v), k0 + 2 * i + 1);
+        pr[i] = ((unsigned long long)hi << 32) | lo;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+template <typename T2>
+__device__ __forceinline__ T2 pk_fma_s(T2 w, unsigned long long pr, T2 acc) {
+    asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(w), "s"(pr));
+    return acc;
+}
+
+// ---- the recurrent 64-term dot product without lane reads: acc += v[lane i of my 16-lane row] * w  (DPP row_newbcast)
+// Four registers hold the 64 broadcast values row-replicated (H[j][lane] = value[16 j + lane % 16]); product (j, i) is ONE
+// v_fmac_f32_dpp.  Measured on one wave per SIMD (tests/diag/dpp_gemv.hip): 390 cycles per 64 products against 494 for
+// 32 v_readlane + 32 v_pk_fma_f32 with scalar operand pairs (a lone wave issues a packed fp32 FMA every 8 cycles, not 4).
+// sixteen products with the sixteen lanes of the row as ONE asm statement (hipcc pads every statement boundary with a wait state
+// whose cost is an issue slot of the lone wave: 64 single-instruction statements carried 14 s_nop per step)
+template <int J>
+__device__ __forceinline__ void fmac_row16(float (&acc)[4], float H, const float (&w)[64]) {
+    asm volatile(
+        "v_fmac_f32_dpp %0, %4, %5 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %1, %4, %6 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %2, %4, %7 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %3, %4, %8 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %0, %4, %9 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %1, %4, %10 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %2, %4, %11 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %3, %4, %12 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %0, %4, %13 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %1, %4, %14 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %2, %4, %15 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %3, %4, %16 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %0, %4, %17 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %1, %4, %18 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %2, %4, %19 row_newbcast:14 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %3, %4, %20 row_newbcast:15 row_mask:0xf bank_mask:0xf\n\t"
+        : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3])
+        : "v"(H), "v"(w[16 * J]), "v"(w[16 * J + 1]), "v"(w[16 * J + 2]), "v"(w[16 * J + 3]), "v"(w[16 * J + 4]), "v"(w[16 * J + 5]),
+          "v"(w[16 * J + 6]), "v"(w[16 * J + 7]), "v"(w[16 * J + 8]), "v"(w[16 * J + 9]), "v"(w[16 * J + 10]), "v"(w[16 * J + 11]),
+          "v"(w[16 * J + 12]), "v"(w[16 * J + 13]), "v"(w[16 * J + 14]), "v"(w[16 * J + 15]));
+}
+__device__ __forceinline__ float dot64_rowbcast(const float (&H)[4], const float (&w)[64]) {
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    // a DPP read needs two wait states behind a VALU write of its source (the swaps of rows_replicate); the compiler pads only
+    // what it can see, not the inside of an asm statement
+    asm volatile("s_nop 1" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
+    fmac_row16<0>(acc, H[0], w); fmac_row16<1>(acc, H[1], w); fmac_row16<2>(acc, H[2], w); fmac_row16<3>(acc, H[3], w);
+    return (acc[0] + acc[1]) + (acc[2] + acc[3]);
+}
+// where value k of the broadcast vector sits in its 64-float LDS line: lane l reads ONE float4 at 4 (l % 16) and has H[0..3]
+__device__ __forceinline__ int rowbcast_slot(int k) { return (k & 15) * 4 + (k >> 4); }
+// the same four registers from a value held lane-wise (lane l has value[l]): three half / row swaps, no LDS
+__device__ __forceinline__ void rows_replicate(float v, float (&H)[4]) {
+    const unsigned x = __float_as_uint(v);
+    const auto r32 = __builtin_amdgcn_permlane32_swap(x, x, false, false);    // [r0 r1 r0 r1], [r2 r3 r2 r3]
+    const auto a = __builtin_amdgcn_permlane16_swap(r32[0], r32[0], false, false);   // [r0 x4], [r1 x4]
+    const auto b = __builtin_amdgcn_permlane16_swap(r32[1], r32[1], false, false);   // [r2 x4], [r3 x4]
+    H[0] = __uint_as_float(a[0]); H[1] = __uint_as_float(a[1]); H[2] = __uint_as_float(b[0]); H[3] = __uint_as_float(b[1]);
+}
+
 #ifndef WM_LSTM_HS_BWD
 #define WM_LSTM_HS_BWD 64       // measured: 32 -> 7.84 ms, 48 -> 7.65 ms, 64 (no LDS round trip at all) -> 7.53 ms
 #endif
@@ -164,12 +244,16 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(const float* xp, const fl
 #pragma unroll
                 for (int k = 0; k < (64 - HS) / 4; ++k) hq[k] = hp[HS / 4 + k];
                 v2f a01 = v2f{xin[s], 0.f}, a23 = v2f{0.f, 0.f}, b01 = a23, b23 = a23;
+                {
+                    unsigned long long hp[HS / 2];
+                    lanes_to_sgprs<HS>(hv, 0, hp);
 #pragma unroll
-                for (int k = 0; k < HS; k += 8) {
-                    a01 = pk_fma_lanes(wr[k / 2], hv, k, a01);
-                    a23 = pk_fma_lanes(wr[k / 2 + 1], hv, k + 2, a23);
-                    b01 = pk_fma_lanes(wr[k / 2 + 2], hv, k + 4, b01);
-                    b23 = pk_fma_lanes(wr[k / 2 + 3], hv, k + 6, b23);
+                    for (int k = 0; k < HS; k += 8) {
+                        a01 = pk_fma_s(wr[k / 2], hp[k / 2], a01);
+                        a23 = pk_fma_s(wr[k / 2 + 1], hp[k / 2 + 1], a23);
+                        b01 = pk_fma_s(wr[k / 2 + 2], hp[k / 2 + 2], b01);
+                        b23 = pk_fma_s(wr[k / 2 + 3], hp[k / 2 + 3], b23);
+                    }
                 }
 #pragma unroll
                 for (int k = 0; k < (64 - HS) / 4; k += 2) {
@@ -236,12 +320,11 @@ __global__ __launch_bounds__(256) void lstm_fwd_fused_kernel(const float* __rest
     float* hsm = reinterpret_cast<float*>(Xb + NP * CH * PITCH);                      // [2][64]
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
     const int q = lane & 3, ul = lane >> 2, u = wave * 16 + ul, n = q * 64 + u, np = wave * 64 + lane;
-    v2f wr[32];                                    // W_hh row n of this lane
+    float wr[64];                                  // W_hh row n of this lane
 #pragma unroll
     for (int k = 0; k < 64; k += 4) {
         const float4 v = *reinterpret_cast<const float4*>(w_hh + n * 64 + k);
-        wr[k / 2] = v2f{v.x, v.y};
-        wr[k / 2 + 1] = v2f{v.z, v.w};
+        wr[k] = v.x; wr[k + 1] = v.y; wr[k + 2] = v.z; wr[k + 3] = v.w;
     }
     // W_ih A fragments: row i = l31 of m-tile mt <-> gate column n' = wave*64 + mt*32 + l31, k = 16 ks + 8 half + j
     bf16x8 Wi[2][4][NP];
@@ -325,6 +408,9 @@ __global__ __launch_bounds__(256) void lstm_fwd_fused_kernel(const float* __rest
 
     float hk[4];
     int t0 = 0, cbuf = 0;
+#ifdef WM_STAMP
+    unsigned long long tm[6] = {0, 0, 0, 0, 0, 0};
+#endif
     // eight steps of the chunk with compile-time positions s = 8*SUB + j (register-array indices must be constants)
     auto run8 = [&](auto sub_c) {
         constexpr int SUB = decltype(sub_c)::value;
@@ -337,36 +423,25 @@ __global__ __launch_bounds__(256) void lstm_fwd_fused_kernel(const float* __rest
             if (s >= 2 && s < 26) mfma_one(2 * (s - 2));
             if (s == 28) store_xp(cbuf ^ 1);
             if (t < T) {                                   // uniform across the workgroup
+                LSTAMP(ls0, c);
                 const float xin = xps[(cbuf * CH + s) * XPP + np] + bias;
                 const float* hcur = hsm + (s & 1) * 64;
-                const float hv = hcur[lane & (HS - 1)];
-                const float4* hp = reinterpret_cast<const float4*>(hcur);
-                float4 hq[(64 - HS) / 4];
-#pragma unroll
-                for (int k = 0; k < (64 - HS) / 4; ++k) hq[k] = hp[HS / 4 + k];
-                v2f a01 = v2f{0.f, 0.f}, a23 = a01, b01 = a01, b23 = a01;     // xin joins at the end: its LDS read stays off the chain's head
-#pragma unroll
-                for (int k = 0; k < HS; k += 8) {
-                    a01 = pk_fma_lanes(wr[k / 2], hv, k, a01);
-                    a23 = pk_fma_lanes(wr[k / 2 + 1], hv, k + 2, a23);
-                    b01 = pk_fma_lanes(wr[k / 2 + 2], hv, k + 4, b01);
-                    b23 = pk_fma_lanes(wr[k / 2 + 3], hv, k + 6, b23);
-                }
-#pragma unroll
-                for (int k = 0; k < (64 - HS) / 4; k += 2) {
-                    const float4 h0 = hq[k], h1 = hq[k + 1];
-                    a01 = __builtin_elementwise_fma(wr[HS / 2 + 2 * k], v2f{h0.x, h0.y}, a01);
-                    a23 = __builtin_elementwise_fma(wr[HS / 2 + 2 * k + 1], v2f{h0.z, h0.w}, a23);
-                    b01 = __builtin_elementwise_fma(wr[HS / 2 + 2 * k + 2], v2f{h1.x, h1.y}, b01);
-                    b23 = __builtin_elementwise_fma(wr[HS / 2 + 2 * k + 3], v2f{h1.z, h1.w}, b23);
-                }
+                const float4 hq4 = *reinterpret_cast<const float4*>(hcur + 4 * (lane & 15));   // h(t-1), row-replicated: one read per lane
+                float Hh[4] = {hq4.x, hq4.y, hq4.z, hq4.w};
+                float hv = Hh[0];
+                LSTAMP(ls1, hv);                           // h of the previous step is in registers (LDS read latency)
+                Hh[0] = hv;
                 if (s >= 2 && s < 26) mfma_one(2 * (s - 2) + 1);
-                const v2f sm = (a01 + a23) + (b01 + b23);
-                const float act = gate_act((sm.x + sm.y) + xin, is_g);
+                const float dotp = dot64_rowbcast(Hh, wr);
+                float pre = dotp + xin;
+                LSTAMP(ls2, pre);                          // 64-term dot product of the lane's gate row done
+                float act = gate_act(pre, is_g);
+                LSTAMP(ls3, act);                          // gate activation (exp + rcp)
                 const float gi = quad_bcast<0>(act), gf = quad_bcast<1>(act), gg = quad_bcast<2>(act), go = quad_bcast<3>(act);
                 c = fmaf(gf, c, gi * gg);
-                const float h = go * tanh_s(c);
-                if (q == 0) hsm[((s + 1) & 1) * 64 + u] = h;
+                float h = go * tanh_s(c);
+                LSTAMP(ls4, h);                            // quad exchange, cell update, tanh(c)
+                hsm[((s + 1) & 1) * 64 + rowbcast_slot(u)] = h;            // the four lanes of a quad hold the same h: no lane mask
                 if (SAVE) {
                     gb[(size_t)t * 256] = act;             // one contiguous 256-B segment per wave
                     if (q == 1) cb[(size_t)t * 64] = c;
@@ -374,7 +449,11 @@ __global__ __launch_bounds__(256) void lstm_fwd_fused_kernel(const float* __rest
                 if (((s >> 2) & 3) == q) hk[s & 3] = h;
                 if ((s & 15) == 15)                        // every lane holds h for steps 4q .. 4q+3 of this 16-step group
                     *reinterpret_cast<float4*>(hb + t0 + (s - 15) + 4 * q) = make_float4(hk[0], hk[1], hk[2], hk[3]);
+                LSTAMP(ls5, h);                            // h to LDS, saved activations / outputs issued
                 __syncthreads();
+                LSTAMP(ls6, c);                            // barrier
+                LSTAMP_ACC(0, ls0, ls1); LSTAMP_ACC(1, ls1, ls2); LSTAMP_ACC(2, ls2, ls3); LSTAMP_ACC(3, ls3, ls4);
+                LSTAMP_ACC(4, ls4, ls5); LSTAMP_ACC(5, ls5, ls6);
             }
         }
     };
@@ -391,6 +470,13 @@ __global__ __launch_bounds__(256) void lstm_fwd_fused_kernel(const float* __rest
                 if (tq0 + j < T) hb[tq0 + j] = hk[j];
         }
     }
+#ifdef WM_STAMP
+    if (g_lstm_stamp && lane == 0) {
+        unsigned long long* d = g_lstm_stamp + ((size_t)blockIdx.x * 4 + wave) * 6;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) d[i] = tm[i];
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------- recurrence bwd
@@ -399,17 +485,13 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(float* __restrict__ gates
                                                        const float* __restrict__ dh_out, const float* __restrict__ w_hh,
                                                        int T) {
     __builtin_amdgcn_s_setprio(3);   // latency-bound recurrence: win issue arbitration against co-resident weight-gradient waves
-    constexpr int HS = WM_LSTM_HS_BWD;
-    __shared__ __align__(16) float das[4][64];      // wave-private da vectors
     __shared__ __align__(16) float part[2][64][4];  // [buffer][k][wave] partial dh
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q = lane & 3, ul = lane >> 2, u = wave * 16 + ul, np = wave * 64 + lane;
     // transposed-product operand: lane = output k, register j = the gate row held by lane j of this wave
-    v2f wt[32];
+    float wt[64];
 #pragma unroll
-    for (int j = 0; j < 64; j += 2)
-        wt[j / 2] = v2f{w_hh[((j & 3) * 64 + wave * 16 + (j >> 2)) * 64 + lane],
-                        w_hh[(((j + 1) & 3) * 64 + wave * 16 + ((j + 1) >> 2)) * 64 + lane]};
+    for (int j = 0; j < 64; ++j) wt[j] = w_hh[((j & 3) * 64 + wave * 16 + (j >> 2)) * 64 + lane];
     if (tid < 512 / 4) reinterpret_cast<float4*>(&part[0][0][0])[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
     float dc = 0.f;
     float* gb = gates + (size_t)b * T * 256 + np;
@@ -431,52 +513,48 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(float* __restrict__ gates
 #pragma unroll
         for (int j = 0; j <= CH; ++j) f.cc[j] = cb[(size_t)max(t1 - CH + j, 0) * 64];
     };
+    const bool is0 = q == 0, is1 = q == 1, is2 = q == 2, is3 = q == 3;
     int pb = 0;   // partial buffer parity
+#ifdef WM_STAMP
+    unsigned long long tm[6] = {0, 0, 0, 0, 0, 0};
+#endif
     auto run_chunk = [&](const Buf& f, int t1) {
 #pragma unroll
         for (int jj = 0; jj < CH; ++jj) {
             const int j = CH - 1 - jj, t = t1 - jj;
             if (t >= 0) {
+                LSTAMP(ls0, dc);
                 const float4 p = *reinterpret_cast<const float4*>(&part[pb][u][0]);
-                const float dht = f.dh[j] + ((p.x + p.y) + (p.z + p.w));
+                // everything that does not need dh of this step first (it overlaps the LDS read above), branch-free: a lane's role
+                // (its gate q) only selects operands.  da = base * S * D with  base = dc_t (gates i, f, g) | dh_t (gate o),
+                // S = g | c_{t-1} | i | tanh(c_t),  D = a (1 - a) for the sigmoid gates, 1 - a^2 for g  (a = the lane's own activation)
                 const float act = f.ga[j];
                 const float gi = quad_bcast<0>(act), gf = quad_bcast<1>(act), gg = quad_bcast<2>(act), go = quad_bcast<3>(act);
                 const float tc = tanh_s(f.cc[j + 1]);
                 const float cprev = (t >= 1) ? f.cc[j] : 0.f;
-                const float dct = fmaf(dht * go, 1.f - tc * tc, dc);
-                float da;
-                if (q == 0) da = dct * gg * gi * (1.f - gi);
-                else if (q == 1) da = dct * cprev * gf * (1.f - gf);
-                else if (q == 2) da = dct * gi * (1.f - gg * gg);
-                else da = dht * tc * go * (1.f - go);
+                const float S = is0 ? gg : (is1 ? cprev : (is2 ? gi : tc));
+                const float D = is2 ? fmaf(-act, act, 1.f) : act * (1.f - act);
+                const float M = S * D;
+                const float K = go * fmaf(-tc, tc, 1.f);
+                float dht = f.dh[j] + ((p.x + p.y) + (p.z + p.w));
+                LSTAMP(ls1, dht);                          // the four waves' partial dh read back and summed
+                const float dct = fmaf(dht, K, dc);
+                float da = (is3 ? dht : dct) * M;
                 dc = dct * gf;
+                LSTAMP(ls2, da);                           // quad exchange, tanh(c), gate derivatives
                 gb[(size_t)t * 256] = da;
-                if (HS < 64) {
-                    das[wave][lane] = da;                   // same wave reads it back: no barrier needed
-                    __builtin_amdgcn_wave_barrier();
-                }
-                // the wave's own 64 da values: the first HS straight out of the register (v_readlane -> SGPR-pair FMA
-                // operands), the rest as broadcast LDS reads -- VALU and the LDS return path share the load (see lstm_fwd)
-                const float4* dp = reinterpret_cast<const float4*>(das[wave]);
-                float4 dq[HS < 64 ? (64 - HS) / 4 : 1];
-#pragma unroll
-                for (int k = 0; k < (64 - HS) / 4; ++k) dq[k] = dp[HS / 4 + k];
-                v2f a01 = v2f{0.f, 0.f}, a23 = a01;
-#pragma unroll
-                for (int k = 0; k < HS; k += 4) {
-                    a01 = pk_fma_lanes(wt[k / 2], da, k, a01);
-                    a23 = pk_fma_lanes(wt[k / 2 + 1], da, k + 2, a23);
-                }
-#pragma unroll
-                for (int k = 0; k < (64 - HS) / 4; ++k) {
-                    const float4 d = dq[k];
-                    a01 = __builtin_elementwise_fma(wt[HS / 2 + 2 * k], v2f{d.x, d.y}, a01);
-                    a23 = __builtin_elementwise_fma(wt[HS / 2 + 2 * k + 1], v2f{d.z, d.w}, a23);
-                }
-                const v2f sm = a01 + a23;
-                part[pb ^ 1][lane][wave] = sm.x + sm.y;
+                // lane k's partial dh[k] over the wave's own 64 gate rows: da row-replicated by three half / row swaps, then 64 products
+                // with the DPP row broadcast (no lane reads, no LDS round trip)
+                float Dd[4];
+                rows_replicate(da, Dd);
+                float psum = dot64_rowbcast(Dd, wt);
+                LSTAMP(ls3, psum);                         // W_hh^T da over the wave's 64 gate rows (readlane + pk_fma)
+                part[pb ^ 1][lane][wave] = psum;
                 pb ^= 1;
+                LSTAMP(ls4, psum);
                 __syncthreads();
+                LSTAMP(ls5, dc);
+                LSTAMP_ACC(0, ls0, ls1); LSTAMP_ACC(1, ls1, ls2); LSTAMP_ACC(2, ls2, ls3); LSTAMP_ACC(3, ls3, ls4); LSTAMP_ACC(4, ls4, ls5);
             }
         }
     };
@@ -488,6 +566,13 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(float* __restrict__ gates
         prefetch(A, t1 - 2 * CH);
         run_chunk(Bf, t1 - CH);
     }
+#ifdef WM_STAMP
+    if (g_lstm_stamp && lane == 0) {
+        unsigned long long* d = g_lstm_stamp + ((size_t)blockIdx.x * 4 + wave) * 6;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) d[i] = tm[i];
+    }
+#endif
 }
 
 // --------------------------------------------------- recurrence bwd with the input gradient inside
@@ -632,10 +717,17 @@ __global__ __launch_bounds__(256) void lstm_bwd_fused_kernel(float* __restrict__
                     d[0] = (unsigned short)p0; d[CHK * PITCH] = (unsigned short)p1; d[2 * CHK * PITCH] = (unsigned short)p2;
                 }
                 v2f a01 = v2f{0.f, 0.f}, a23 = a01;
+                // two batches of 32 lane reads, each ahead of its 16 products (64 scalar registers at once would not fit beside the rest)
 #pragma unroll
-                for (int k = 0; k < HS; k += 4) {
-                    a01 = pk_fma_lanes(wt[k / 2], da, k, a01);
-                    a23 = pk_fma_lanes(wt[k / 2 + 1], da, k + 2, a23);
+                for (int k0 = 0; k0 < HS; k0 += 32) {
+                    constexpr int NB = HS < 32 ? HS : 32;
+                    unsigned long long dp[NB / 2];
+                    lanes_to_sgprs<NB>(da, k0, dp);
+#pragma unroll
+                    for (int k = 0; k < NB; k += 4) {
+                        a01 = pk_fma_s(wt[(k0 + k) / 2], dp[k / 2], a01);
+                        a23 = pk_fma_s(wt[(k0 + k) / 2 + 1], dp[k / 2 + 1], a23);
+                    }
                 }
 #pragma unroll
                 for (int k = 0; k < (64 - HS) / 4; ++k) {
@@ -1072,6 +1164,12 @@ __global__ void lstm_wgrad_reduce_kernel(const float* __restrict__ partial, int 
 }  // namespace
 
 extern "C" {
+
+#ifdef WM_STAMP
+int wm_debug_set_lstm_stamp_buffer(unsigned long long* buf) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_lstm_stamp), &buf, sizeof(buf));
+}
+#endif
 
 // xp [B,T,256] = x[B,64,T]^T W_ih^T + b_ih + b_hh
 int wm_lstm_xproj(const float* x, const float* w_ih, const float* b_ih, const float* b_hh, float* xp, int B, int T,
