@@ -3255,12 +3255,24 @@ __global__ __launch_bounds__(256) void dwgrad64bf_kernel(DWArgs a) {
     // sums are one register each instead of sixteen.
     float s1 = 0.f, s2 = 0.f;
     f32x4 e1q[4];
+    // conv2 pair: the epilogue operand IS the input operand of the weight gradient (the pre-BatchNorm activation), read a second
+    // time in the accumulator layout.  Fetched one tile AHEAD (e1n, for the next tile, while this one is in phase A) it follows
+    // the staging loads of the same tile by less than one tile's worth of traffic and is served by the XCD's L2 instead of HBM
+    // (fetched as late as the tile needs it, 32 % of the kernel's HBM traffic was this re-read).
+    constexpr bool EAHEAD = (EPI == EPI_RELUMASK);
+    f32x4 e1n[EAHEAD ? 4 : 1];
     unsigned emk = 0u;
     const float kea = (EPI == EPI_RELUMASK) ? Cs[384 + 32 * mt + l31] : 0.f, keb = (EPI == EPI_RELUMASK) ? Cs[448 + 32 * mt + l31] : 0.f;
     int buf = 0;
 #ifdef WM_STAMP
     unsigned long long tm[6] = {0, 0, 0, 0, 0, 0};
 #endif
+    if (EAHEAD) {                                        // the first tile's epilogue operand
+        const int b0 = tile / tilesPerClip, t00 = (tile - b0 * tilesPerClip) * NT;
+        const wm_srd_t s0 = make_srd(a.e1 + ((size_t)b0 * 64 + 32 * mt) * T, (size_t)32 * T * sizeof(float));
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) e1q[q4] = buf_load4(s0, (unsigned)(l31 * T + t00 + 32 * nh + 4 * half) * 4u + 32u * q4, 0u);
+    }
 #define FENCE __builtin_amdgcn_sched_barrier(0)
     while (tile < ntiles) {
         // registers: the raw operands of tile + tstep (clamped: the duplicate of the last tile is split but never used)
@@ -3278,6 +3290,9 @@ __global__ __launch_bounds__(256) void dwgrad64bf_kernel(DWArgs a) {
         const wm_srd_t sye = make_srd(a.y + slab, (size_t)32 * T * sizeof(float));
         const wm_srd_t se1 = make_srd(a.e1 + slab, (size_t)32 * T * sizeof(float));
         const unsigned eoff = (unsigned)(l31 * T + t0 + 32 * nh + 4 * half) * 4u;
+        const int tnx = min(tile + tstep, ntiles - 1), bnx = tnx / tilesPerClip, t0nx = (tnx - bnx * tilesPerClip) * NT;
+        const wm_srd_t se1n = EAHEAD ? make_srd(a.e1 + ((size_t)bnx * 64 + 32 * mt) * T, (size_t)32 * T * sizeof(float)) : se1;
+        const unsigned eoffn = (unsigned)(l31 * T + t0nx + 32 * nh + 4 * half) * 4u;
         // GM, conv1 pair: e1 is the gradient that reaches the block output; its ReLU bits: dword t0 / 32 + nh of the lane's row
         constexpr bool GME = GM && EPI == EPI_ADD;
         const wm_srd_t sme = GME ? make_srd(reinterpret_cast<const float*>(a.gmask) + ((size_t)b * 64 + 32 * mt) * nwm,
@@ -3313,7 +3328,10 @@ __global__ __launch_bounds__(256) void dwgrad64bf_kernel(DWArgs a) {
                     FENCE;
                     const int m = s * 6 + j;                         // 0..71
                     if (m < NSA) { sideA(m, Gn, Xn); refillA(m); }
-                    else if (((m - NSA) & 1) == 0) e1q[(m - NSA) >> 1] = buf_load4(se1, eoff + 32u * ((m - NSA) >> 1), 0u);
+                    else if (((m - NSA) & 1) == 0) {
+                        if (EAHEAD) e1n[(m - NSA) >> 1] = buf_load4(se1n, eoffn + 32u * ((m - NSA) >> 1), 0u);
+                        else e1q[(m - NSA) >> 1] = buf_load4(se1, eoff + 32u * ((m - NSA) >> 1), 0u);
+                    }
                     else if (GME && m == NSA + 1) emk = __builtin_bit_cast(unsigned, buf_load(sme, emoff, 0u));
                     FENCE;
                 }
@@ -3413,6 +3431,10 @@ __global__ __launch_bounds__(256) void dwgrad64bf_kernel(DWArgs a) {
                 FENCE;
             }
             okh_cur = okh_n; hsh_cur = hsh_n;
+            if (EAHEAD) {
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) e1q[q4] = e1n[q4];
+            }
         }
         STAMP(ts3);
         lds_barrier();          // image D of the next tile is complete; images G', X' of this tile are free

@@ -6,6 +6,10 @@ so = os.environ.get("WM_STAMP_LIB") or os.path.join(ROOT, "audio-watermarking-de
 L = ctypes.CDLL(so)
 dev = torch.device("cuda:0"); B, T = int(sys.argv[1]) if len(sys.argv) > 1 else 256, 16000
 dz = torch.randn(B, 64, T, device=dev); y2 = torch.randn(B, 64, T, device=dev); y1 = torch.randn(B, 64, T, device=dev)
+if len(sys.argv) > 2 and sys.argv[2] == "zeros":        # same instruction stream on all-zero operands: the clock the chip then holds
+    dz.zero_(); y2.zero_(); y1.zero_()                  # separates power-limited from issue-limited time
+if len(sys.argv) > 2 and sys.argv[2] == "sparse":       # ReLU-like operands (half of the activations zero)
+    y1.clamp_(min=0); dz.mul_((torch.rand_like(dz) > 0.5).float())
 out = torch.empty_like(dz)
 w = torch.randn(64, 64, 3, device=dev) * 0.05
 k = torch.rand(4, 64, device=dev); sc = torch.rand(64, device=dev) + 0.5; sh = torch.randn(64, device=dev) * 0.1
