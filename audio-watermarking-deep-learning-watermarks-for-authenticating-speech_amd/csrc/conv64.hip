@@ -27,7 +27,8 @@ namespace {
 
 enum { PRO_NONE = 0, PRO_BNRELU = 1, PRO_ADDVEC = 2, PRO_BNBWD = 3 };
 enum { EPI_BIAS = 0, EPI_RELUMASK = 1, EPI_ADD = 2, EPI_NONE = 3, EPI_BNADDRELU = 4,    // 4: relu(e1 + (acc + bias) * ea + eb), conv64bf3 only
-       EPI_BIASELU = 5, EPI_BIASADDELU = 6, EPI_MULDELU = 7 };   // main14b_2's 64-channel blocks (conv64bf_kernel only): elu(acc + bias),
+       EPI_BIASELU = 5, EPI_BIASADDELU = 6, EPI_MULDELU = 7,
+       EPI_ADDSTATS = 8 };    // dwgrad64bf only: EPI_ADD, then the ReLU mask of the PREVIOUS block and its two BatchNorm sums   // main14b_2's 64-channel blocks (conv64bf_kernel only): elu(acc + bias),
                                                                  // elu(acc + bias + e1), acc * ELU'(e1) with e1 = the ELU output y
 
 struct Conv64Args {
@@ -2935,13 +2936,16 @@ struct DWArgs {
     int B, T;
     const unsigned* gmask;                              // GM: sign bits of the ReLU the incoming gradient passes (bit t % 32 of dword
                                                         // [row][t / 32]): applied to g (conv2 pair) / to e1 (conv1 pair) on load
+    const unsigned* pmask; const float* py2;            // EPI_ADDSTATS: sign bits / pre-BatchNorm activation y2 of the block BEFORE this
+                                                        // one: y = (data gradient + e1) masked, stats = (sum y, sum y py2)
 };
 
 template <int EPI, int XPRO, bool GM>
 __global__ __launch_bounds__(256) void dwgrad64bf_kernel(DWArgs a) {
-    static_assert((EPI == EPI_RELUMASK && XPRO == PRO_BNRELU) || (EPI == EPI_ADD && XPRO == PRO_NONE), "conv2 pair or conv1 pair");
+    static_assert((EPI == EPI_RELUMASK && XPRO == PRO_BNRELU) || ((EPI == EPI_ADD || EPI == EPI_ADDSTATS) && XPRO == PRO_NONE), "conv2 pair or conv1 pair");
     constexpr int KW = 3, NT = 64, NP = 3, ROWS = NT + 2, PITCH = 72, PG = 72, PX = 88, XO = 8;
-    constexpr bool STATS = (EPI == EPI_RELUMASK);
+    constexpr bool STATS = (EPI == EPI_RELUMASK || EPI == EPI_ADDSTATS);
+    constexpr bool FOLD = (EPI == EPI_ADDSTATS);          // conv1 pair that also does the previous block's ReLU backward + BN sums
     constexpr int DIMG = NP * ROWS * PITCH, GIMG = NP * 64 * PG, XIMG = NP * 64 * PX;
     extern __shared__ __align__(16) unsigned char smem_raw[];
     unsigned short* Db = reinterpret_cast<unsigned short*>(smem_raw);          // [NP][ROWS][PITCH]   row r = time t0 - 1 + r
@@ -3261,7 +3265,8 @@ __global__ __launch_bounds__(256) void dwgrad64bf_kernel(DWArgs a) {
     // (fetched as late as the tile needs it, 32 % of the kernel's HBM traffic was this re-read).
     constexpr bool EAHEAD = (EPI == EPI_RELUMASK);
     f32x4 e1n[EAHEAD ? 4 : 1];
-    unsigned emk = 0u;
+    unsigned emk = 0u, pmk = 0u;
+    f32x4 pyq[FOLD ? 4 : 1];
     const float kea = (EPI == EPI_RELUMASK) ? Cs[384 + 32 * mt + l31] : 0.f, keb = (EPI == EPI_RELUMASK) ? Cs[448 + 32 * mt + l31] : 0.f;
     int buf = 0;
 #ifdef WM_STAMP
@@ -3294,7 +3299,10 @@ __global__ __launch_bounds__(256) void dwgrad64bf_kernel(DWArgs a) {
         const wm_srd_t se1n = EAHEAD ? make_srd(a.e1 + ((size_t)bnx * 64 + 32 * mt) * T, (size_t)32 * T * sizeof(float)) : se1;
         const unsigned eoffn = (unsigned)(l31 * T + t0nx + 32 * nh + 4 * half) * 4u;
         // GM, conv1 pair: e1 is the gradient that reaches the block output; its ReLU bits: dword t0 / 32 + nh of the lane's row
-        constexpr bool GME = GM && EPI == EPI_ADD;
+        constexpr bool GME = GM && (EPI == EPI_ADD || EPI == EPI_ADDSTATS);
+        const wm_srd_t spm = FOLD ? make_srd(reinterpret_cast<const float*>(a.pmask) + ((size_t)b * 64 + 32 * mt) * nwm,
+                                             (size_t)32 * nwm * sizeof(unsigned)) : se1;
+        const wm_srd_t spy = FOLD ? make_srd(a.py2 + slab, (size_t)32 * T * sizeof(float)) : se1;
         const wm_srd_t sme = GME ? make_srd(reinterpret_cast<const float*>(a.gmask) + ((size_t)b * 64 + 32 * mt) * nwm,
                                             (size_t)32 * nwm * sizeof(unsigned)) : se1;
         const unsigned emoff = ((unsigned)l31 * nwm + ((unsigned)t0 >> 5) + (unsigned)nh) * 4u;
@@ -3333,6 +3341,7 @@ __global__ __launch_bounds__(256) void dwgrad64bf_kernel(DWArgs a) {
                         else e1q[(m - NSA) >> 1] = buf_load4(se1, eoff + 32u * ((m - NSA) >> 1), 0u);
                     }
                     else if (GME && m == NSA + 1) emk = __builtin_bit_cast(unsigned, buf_load(sme, emoff, 0u));
+                    else if (FOLD && m == NSA + 3) pmk = __builtin_bit_cast(unsigned, buf_load(spm, emoff, 0u));
                     FENCE;
                 }
             }
@@ -3398,6 +3407,16 @@ __global__ __launch_bounds__(256) void dwgrad64bf_kernel(DWArgs a) {
                 } else {
                     v0 += q0_; v1 += q1_;
                 }
+                if (FOLD) {
+                    // what leaves is dz2 of the PREVIOUS block: its output's ReLU mask on the gradient just formed, and the two sums its
+                    // BatchNorm backward needs (sum dz2, sum dz2 y2) -- that block then has no reduction pass of its own
+                    if (i == 0) pmk >>= 4 * half;
+                    v0 = __uint_as_float(__float_as_uint(v0) & (unsigned)__builtin_amdgcn_sbfe((int)pmk, 8 * (r0 >> 2) + (r0 & 3), 1));
+                    v1 = __uint_as_float(__float_as_uint(v1) & (unsigned)__builtin_amdgcn_sbfe((int)pmk, 8 * (r1 >> 2) + (r1 & 3), 1));
+                    s1 += v0; s2 = fmaf(v0, pyq[r0 >> 2][r0 & 3], s2);
+                    s1 += v1; s2 = fmaf(v1, pyq[r1 >> 2][r1 & 3], s2);
+                    asm volatile("" : "+v"(s1), "+v"(s2));
+                }
                 dacc[r0] = v0; dacc[r1] = v1;
                 if (i & 1) {
                     const int q4 = i >> 1;
@@ -3424,7 +3443,10 @@ __global__ __launch_bounds__(256) void dwgrad64bf_kernel(DWArgs a) {
                 else {
                     // 48 free slices: image D of the next tile in every second one of the first 24, the epilogue quads in the last 24
                     const int v = kb * 12 + (mm - 6);             // 0..47
-                    if (v < 2 * NSB) { if ((v & 1) == 0) sideB(v >> 1); else refillB(v); }
+                    if (v < 2 * NSB) {
+                        if ((v & 1) == 0) sideB(v >> 1); else refillB(v);
+                        if (FOLD && (v == 3 || v == 9 || v == 15 || v == 21)) pyq[(v - 3) / 6] = buf_load4(spy, eoff + 32u * ((v - 3) / 6), 0u);
+                    }
                     else if (v >= 24 && ((v - 24) % 3) == 0) epi2((v - 24) / 3);
                 }
                 if (mm == 12 && kb + 1 < 4) read_kb(kb + 1, set ^ 1);
@@ -3671,12 +3693,15 @@ int wm_dwgrad64_bf(const float* g, const float* g2, const float* ga, const float
                    const void* gmask, hipStream_t stream) {
     if (B <= 0 || T <= 0 || (T & 63)) return (int)hipErrorInvalidValue;
     if (!g || !g2 || !ga || !gb || !gc || !wpb || !x || !e1 || !y || !partial || !dw) return (int)hipErrorInvalidValue;
-    DWArgs a{g, g2, ga, gb, gc, wpb, x, xa, xb, e1, ea, eb, y, stats, partial, B, T, reinterpret_cast<const unsigned*>(gmask)};
+    DWArgs a{g, g2, ga, gb, gc, wpb, x, xa, xb, e1, ea, eb, y, stats, partial, B, T, reinterpret_cast<const unsigned*>(gmask),
+             epi == EPI_ADDSTATS ? reinterpret_cast<const unsigned*>(eb) : nullptr, epi == EPI_ADDSTATS ? ea : nullptr};
     int grid = 0, rc = (int)hipErrorInvalidValue;
     if (epi == EPI_RELUMASK && xpro == PRO_BNRELU && stats && xa && xb && ea && eb)
         rc = gmask ? launch_dwgrad64bf<EPI_RELUMASK, PRO_BNRELU, true>(a, &grid, stream) : launch_dwgrad64bf<EPI_RELUMASK, PRO_BNRELU, false>(a, &grid, stream);
     else if (epi == EPI_ADD && xpro == PRO_NONE && !stats)
         rc = gmask ? launch_dwgrad64bf<EPI_ADD, PRO_NONE, true>(a, &grid, stream) : launch_dwgrad64bf<EPI_ADD, PRO_NONE, false>(a, &grid, stream);
+    else if (epi == EPI_ADDSTATS && xpro == PRO_NONE && stats && ea && eb && gmask)
+        rc = launch_dwgrad64bf<EPI_ADDSTATS, PRO_NONE, true>(a, &grid, stream);
     if (rc) return rc;
     const int n = 3 * 4096 + 64;
     hipLaunchKernelGGL(wgrad64_reduce_kernel, dim3((n + 63) / 64), dim3(256), 0, stream, (const float*)partial, grid, 3, 0, dw,

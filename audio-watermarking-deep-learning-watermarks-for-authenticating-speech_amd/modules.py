@@ -37,6 +37,24 @@ class ResBlock(nn.Module):
                                     n2.running_mean, n2.running_var, n2.num_batches_tracked, self.training)
 
 
+def _rb_args(m):
+    c1, n1, _, c2, n2 = m.block
+    return (c1.weight, c1.bias, n1.weight, n1.bias, c2.weight, c2.bias, n2.weight, n2.bias,
+            n1.running_mean, n1.running_var, n1.num_batches_tracked, n2.running_mean, n2.running_var, n2.num_batches_tracked)
+
+
+def resblock_pair(m1, m2, x):
+    """m2(m1(x)) for two ResBlocks in a row (py/main16.py:135-136, :178-179).  In a training step on the fused path the pair is
+    ONE tape node (ops.ResBlockPairFn: the second block's backward also does the first block's ReLU backward and BatchNorm sums);
+    otherwise -- inference, no gradients wanted, odd clip lengths, any of the knobs off, forward hooks on the blocks -- two calls."""
+    c = ops._CONV
+    if (m1.training and m2.training and torch.is_grad_enabled() and x.is_cuda and x.dim() == 3 and x.shape[-1] % 64 == 0
+            and c["bf16x6"] and c["fused_bwd"] and c["mask_on_load"] and c["pair_fold"] and not ops._ASYNC["on"]
+            and not m1._forward_hooks and not m2._forward_hooks and not m1._forward_pre_hooks and not m2._forward_pre_hooks):
+        return ops.ResBlockPairFn.apply(x, *_rb_args(m1), *_rb_args(m2), True)
+    return m2(m1(x))
+
+
 class _Stem(nn.Conv1d):
     def forward(self, x, grad_rows=None):
         return ops.StemFn.apply(x, self.weight, self.bias, grad_rows)
@@ -60,7 +78,7 @@ class Generator(nn.Module):
         self.decoder = nn.Sequential(nn.ConvTranspose1d(64, 64, 7, padding=3), ResBlock(64), _Head1(64, 1, 1))
 
     def forward(self, s, message=None):
-        x = self.encoder(s)                                                     # (B,64,T)
+        x = resblock_pair(self.encoder[1], self.encoder[2], self.encoder[0](s))  # (B,64,T)
         x = ops.LSTMFn.apply(x, self.lstm.weight_ih_l0, self.lstm.weight_hh_l0, self.lstm.bias_ih_l0, self.lstm.bias_hh_l0)
         vec = None
         if self.message_bits > 0 and message is not None:
@@ -91,12 +109,8 @@ class Detector(nn.Module):
     def forward(self, x, input_grad_rows=None):
         """`input_grad_rows` (optional, not in the reference): only clips [0, input_grad_rows) get an input gradient --
         the train step feeds [watermarked; clean] (py/main16.py:249) and the clean half is data."""
-        if input_grad_rows is None:
-            return self.model(x)
-        x = self.model[0](x, input_grad_rows)
-        for layer in list(self.model)[1:]:
-            x = layer(x)
-        return x
+        x = self.model[0](x) if input_grad_rows is None else self.model[0](x, input_grad_rows)
+        return self.model[3](resblock_pair(self.model[1], self.model[2], x))
 
 
 def load_state_dict_strip_prefix(model, state_dict, prefix="_orig_mod."):

@@ -148,7 +148,8 @@ import os as _os
 _CONV = {"bf16x6": _os.environ.get("WM_CONV_BF16X6", "1") == "1", "schedule": 2,
          "one_launch_eval": _os.environ.get("WM_RESBLOCK_ONE_LAUNCH", "1") == "1",
          "fused_bwd": _os.environ.get("WM_FUSED_BWD", "1") == "1",
-         "mask_on_load": _os.environ.get("WM_MASK_ON_LOAD", "1") == "1"}
+         "mask_on_load": _os.environ.get("WM_MASK_ON_LOAD", "1") == "1",
+         "pair_fold": _os.environ.get("WM_PAIR_FOLD", "1") == "1"}
 
 
 def set_conv_bf_schedule(schedule: int):
@@ -175,6 +176,13 @@ def set_mask_on_load(on: bool):
     """fused ResBlock backward: 1 (default) the masked gradient dz2 = g * (out > 0) is never written -- the reduction pass forms
     only the BatchNorm sums and wm_dwgrad64_bf masks g on load; 0 it is materialised first.  WM_MASK_ON_LOAD=0/1 sets the default."""
     _CONV["mask_on_load"] = bool(on)
+
+
+def set_pair_fold(on: bool):
+    """two ResBlocks in a row (encoder.1 -> encoder.2, model.1 -> model.2) as ONE tape node whose backward lets the second block's
+    conv1 launch also do the first block's ReLU backward and BatchNorm sums (no reduction pass for the first block).
+    WM_PAIR_FOLD=0/1 sets the default; off = two ResBlockFn nodes."""
+    _CONV["pair_fold"] = bool(on)
 
 
 def set_resblock_one_launch(on: bool):
@@ -266,7 +274,9 @@ class ResBlockFn(GradAwareFunction):
             lib.wm_bn_add_relu(_p(x), _p(y2), _p(sc2), _p(sh2), _p(out), B, T, st)
         ctx.training = bool(training)
         ctx.gdst = _gdst(w1, b1, w2, b2)
-        ctx.save_for_backward(x, y1, y2, mask, cst, w1, w2, g1, g2)
+        ctx._wm_saved = (x, y1, y2, mask, cst, w1, w2, g1, g2)
+        if not getattr(ctx, "_wm_pair", False):
+            ctx.save_for_backward(*ctx._wm_saved)
         return out
 
     @staticmethod
@@ -278,13 +288,14 @@ class ResBlockFn(GradAwareFunction):
         dev, st = x.device, _stream()
         ev = 0 if ctx.training else 1
         n = float(B * T)
-        part = _f32(max(B, 1) * 128, device=dev)
         gw1, gb1, gw2, gb2 = ctx.gdst
         side = all(g is not None for g in ctx.gdst)
         fused = _CONV["bf16x6"] and _CONV["fused_bwd"] and not side and T % 64 == 0
-        # dz2 = g_out * (out > 0).  Fused path: never written -- the reduction pass only forms the two BatchNorm sums, and the two
-        # convolution-backward launches mask g_out with the same bits while they load it (wm_dwgrad64_bf's gmask)
-        dz2 = None if (fused and _CONV["mask_on_load"]) else torch.empty_like(x)
+        if fused:
+            dx, grads, _ = _resblock_bwd_fused(ctx.saved_tensors, ctx.training, g_out)
+            return (dx,) + grads + (None,) * 7
+        part = _f32(max(B, 1) * 128, device=dev)
+        dz2 = torch.empty_like(x)
         lib.wm_relu_bwd_reduce_mask(_p(g_out), _p(mask), _p(y2), _p(dz2), _p(part), B, T, st)
         k2 = _f32(4, 64, device=dev)          # A, B (hi), B (lo), C  -- B is handed over as hi + lo words
         dg2, dbe2 = _f32(64, device=dev), _f32(64, device=dev)
@@ -292,20 +303,6 @@ class ResBlockFn(GradAwareFunction):
         # conv2: data gradient (+ ReLU mask + BN1-backward reductions in the epilogue) and weight gradient
         dz1 = torch.empty_like(x)
         stats = _f32(NCU * 128, device=dev)
-        if fused:
-            # data gradient AND weight gradient of each convolution in one launch: the gradient frames are read once
-            gsrc, gm = (g_out, mask) if dz2 is None else (dz2, None)
-            dw2, db2, dw1, db1 = torch.empty_like(w2), _f32(64, device=dev), torch.empty_like(w1), _f32(64, device=dev)
-            wpart = _f32(NCU * (3 * 4096 + 64), device=dev)
-            lib.wm_dwgrad64_bf(_p(gsrc), _p(y2), _p(k2[0]), _p(k2[1]), _p(k2[3]), _p(pack_w64_bf(w2, 1)), _p(y1), _p(sc1), _p(sh1),
-                               _p(y1), _p(sc1), _p(sh1), _p(dz1), _p(stats), _p(wpart), _p(dw2), _p(db2), B, T, 1, 1, 0, _p(gm), st)
-            k1 = _f32(4, 64, device=dev)
-            dg1, dbe1 = _f32(64, device=dev), _f32(64, device=dev)
-            lib.wm_bn_bwd_finalize(_p(stats), NCU, n, _p(g1), _p(mu1), _p(is1), _p(k1[0]), _p(k1[1]), _p(k1[3]), _p(dg1), _p(dbe1), 0, ev, st)
-            dx = torch.empty_like(x)
-            lib.wm_dwgrad64_bf(_p(dz1), _p(y1), _p(k1[0]), _p(k1[1]), _p(k1[3]), _p(pack_w64_bf(w1, 1)), _p(x), None, None,
-                               _p(gsrc), None, None, _p(dx), None, _p(wpart), _p(dw1), _p(db1), B, T, 0, 2, 0, _p(gm), st)
-            return dx, dw1, db1, dg1, dbe1, dw2, db2, dg2, dbe2, None, None, None, None, None, None, None
         _conv3(dz2, y2, w2, 1, k2[0], k2[1], k2[3], None, y1, sc1, sh1, dz1, stats, B, T, 3, 1)
 
         def wgrad2():
@@ -341,6 +338,83 @@ class ResBlockFn(GradAwareFunction):
         else:
             wgrad1()
         return dx, dw1, db1, dg1, dbe1, dw2, db2, dg2, dbe2, None, None, None, None, None, None, None
+
+
+def _resblock_bwd_fused(saved, training, g_out, pre=None, fold=None):
+    """Backward of one ResBlock on the fused path (data + weight gradient of each convolution in one launch, T % 64 == 0).
+    g_out: gradient w.r.t. the block output.  `pre` = stats partials [NCU,2,64] when g_out ALREADY is dz2 = g (out > 0) and its two
+    BatchNorm sums exist (made by the next block's folded conv1 launch): no reduction pass, no mask.  `fold` = (mask, y2) of the
+    block BEFORE this one: the conv1 launch then writes that block's dz2 instead of the plain input gradient and returns its
+    BatchNorm-sum partials as the third value.  Returns (dx, (dw1, db1, dg1, dbe1, dw2, db2, dg2, dbe2), fold partials | None)."""
+    x, y1, y2, mask, cst, w1, w2, g1, g2 = saved
+    sc1, sh1, mu1, is1, sc2, sh2, mu2, is2 = cst.unbind(0)
+    B, _, T = x.shape
+    dev, st = x.device, _stream()
+    ev = 0 if training else 1
+    n = float(B * T)
+    k2 = _f32(4, 64, device=dev)          # A, B (hi), B (lo), C  -- B is handed over as hi + lo words
+    dg2, dbe2 = _f32(64, device=dev), _f32(64, device=dev)
+    if pre is not None:
+        gsrc, gm = g_out, None
+        lib.wm_bn_bwd_finalize(_p(pre), NCU, n, _p(g2), _p(mu2), _p(is2), _p(k2[0]), _p(k2[1]), _p(k2[3]), _p(dg2), _p(dbe2), 0, ev, st)
+    else:
+        # dz2 = g_out * (out > 0) is never written (default): the reduction pass only forms the two BatchNorm sums, and the two
+        # convolution-backward launches mask g_out with the same bits while they load it (wm_dwgrad64_bf's gmask)
+        part = _f32(max(B, 1) * 128, device=dev)
+        dz2 = None if _CONV["mask_on_load"] else torch.empty_like(x)
+        lib.wm_relu_bwd_reduce_mask(_p(g_out), _p(mask), _p(y2), _p(dz2), _p(part), B, T, st)
+        lib.wm_bn_bwd_finalize(_p(part), B, n, _p(g2), _p(mu2), _p(is2), _p(k2[0]), _p(k2[1]), _p(k2[3]), _p(dg2), _p(dbe2), 0, ev, st)
+        gsrc, gm = (g_out, mask) if dz2 is None else (dz2, None)
+    # conv2: data gradient (+ ReLU mask + BN1-backward reductions in the epilogue) and weight gradient
+    dz1 = torch.empty_like(x)
+    stats = _f32(NCU * 128, device=dev)
+    dw2, db2, dw1, db1 = torch.empty_like(w2), _f32(64, device=dev), torch.empty_like(w1), _f32(64, device=dev)
+    wpart = _f32(NCU * (3 * 4096 + 64), device=dev)
+    lib.wm_dwgrad64_bf(_p(gsrc), _p(y2), _p(k2[0]), _p(k2[1]), _p(k2[3]), _p(pack_w64_bf(w2, 1)), _p(y1), _p(sc1), _p(sh1),
+                       _p(y1), _p(sc1), _p(sh1), _p(dz1), _p(stats), _p(wpart), _p(dw2), _p(db2), B, T, 1, 1, 0, _p(gm), st)
+    k1 = _f32(4, 64, device=dev)
+    dg1, dbe1 = _f32(64, device=dev), _f32(64, device=dev)
+    lib.wm_bn_bwd_finalize(_p(stats), NCU, n, _p(g1), _p(mu1), _p(is1), _p(k1[0]), _p(k1[1]), _p(k1[3]), _p(dg1), _p(dbe1), 0, ev, st)
+    dx = torch.empty_like(x)
+    fpart = None
+    if fold is not None and gm is not None:
+        # conv1 pair that also does the PREVIOUS block's ReLU backward and BatchNorm sums (epi 8): dx leaves as that block's dz2
+        pmask, py2 = fold
+        fpart = _f32(NCU * 128, device=dev)
+        lib.wm_dwgrad64_bf(_p(dz1), _p(y1), _p(k1[0]), _p(k1[1]), _p(k1[3]), _p(pack_w64_bf(w1, 1)), _p(x), None, None,
+                           _p(gsrc), _p(py2), _p(pmask), _p(dx), _p(fpart), _p(wpart), _p(dw1), _p(db1), B, T, 0, 8, 0, _p(gm), st)
+    else:
+        lib.wm_dwgrad64_bf(_p(dz1), _p(y1), _p(k1[0]), _p(k1[1]), _p(k1[3]), _p(pack_w64_bf(w1, 1)), _p(x), None, None,
+                           _p(gsrc), None, None, _p(dx), None, _p(wpart), _p(dw1), _p(db1), B, T, 0, 2, 0, _p(gm), st)
+    return dx, (dw1, db1, dg1, dbe1, dw2, db2, dg2, dbe2), fpart
+
+
+class ResBlockPairFn(GradAwareFunction):
+    """Two ResBlocks in a row (py/main16.py:135-136 encoder.1 -> encoder.2, :178-179 model.1 -> model.2) as one tape node.
+    Forward = ResBlockFn's training forward twice.  Backward: the second block's conv1 launch (data + weight gradient) applies the
+    FIRST block's ReLU mask to the gradient it has just formed and accumulates that block's two BatchNorm sums in its epilogue
+    (wm_dwgrad64_bf epi 8), so the first block needs no reduction pass and the gradient between the blocks is written once, masked.
+    Used by modules.resblock_pair when the fused path applies (bf16x6, T % 64 == 0, mask-on-load, gradients wanted)."""
+
+    @staticmethod
+    def forward(ctx, x, *args):
+        p1, p2, training = args[:14], args[14:28], args[28]
+        ctx._wm_pair = True                                  # ResBlockFn.forward then leaves the saving to this node
+        mid = ResBlockFn.forward(ctx, x, *p1, training)
+        ctx.saved1 = ctx._wm_saved                       # (x, y1, y2, mask, cst, w1, w2, g1, g2) of block 1
+        out = ResBlockFn.forward(ctx, mid, *p2, training)
+        ctx.save_for_backward(*(ctx.saved1 + ctx._wm_saved))
+        ctx.training = bool(training)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        sv = ctx.saved_tensors
+        s1_, s2_ = sv[:9], sv[9:]
+        g_out = g_out.contiguous()
+        dmid, grads2, fpart = _resblock_bwd_fused(s2_, ctx.training, g_out, fold=(s1_[3], s1_[2]))
+        dx, grads1, _ = _resblock_bwd_fused(s1_, ctx.training, dmid, pre=fpart)
+        return (dx,) + grads1 + (None,) * 6 + grads2 + (None,) * 6 + (None,)
 
 
 # ------------------------------------------------------------------------------------------ stem / heads

@@ -288,13 +288,14 @@ def kernel_timers(lib, model, mode, bf_mode, batch):
     if not _ops._CONV["fused_bwd"]:
         return [fwd]
     # ResBlock backward: data gradient + weight gradient of one Conv1d(64,64,3) in ONE launch = two GEMMs of 2*64*64*3*T*B flops.
-    # args: dz y A Bc C wpb xin sc sh e1 ea eb dx stats wpart dw db B T pro epi accumulate stream; epi 1 = conv2 pair (reads dz2 y2
-    # y1, writes dz1: 4 frames), epi 2 = conv1 pair (reads dz1 y1 x dz2, writes dx: 5 frames)
+    # args: dz y A Bc C wpb xin sc sh e1 ea eb dx stats wpart dw db B T pro epi accumulate gmask stream; epi 1 = conv2 pair (reads
+    # dz2 y2 y1, writes dz1: 4 frames), epi 2 = conv1 pair (reads dz1 y1 x dz2, writes dx: 5 frames), epi 8 = conv1 pair that also
+    # does the previous block's ReLU backward + BatchNorm sums (one more frame read: 6)
     dw = dict(timer=LaunchTimer(lib, "wm_dwgrad64_bf", lambda a: True,
-                                lambda a: (2.0 * 2.0 * 64 * 64 * 3 * a[18] * a[17], (4.0 if a[20] == 1 else 5.0) * 64 * a[18] * 4 * a[17])),
-              kernel="dwgrad64bf_kernel<1,1> + <2,0> (wm_dwgrad64_bf: data gradient AND weight gradient of a ResBlock Conv1d(64,64,3) in one "
-                     "launch -- BN-backward rebuilt on load, ReLU mask / BN sums / residual add in the epilogue; bf16x6 split products, "
-                     "fp32 accumulate; 30 % of the step's kernel time)",
+                                lambda a: (2.0 * 2.0 * 64 * 64 * 3 * a[18] * a[17], {1: 4.0, 2: 5.0, 8: 6.0}[a[20]] * 64 * a[18] * 4 * a[17])),
+              kernel="dwgrad64bf_kernel<1,1,*> + <2,0,*> + <8,0,true> (wm_dwgrad64_bf: data gradient AND weight gradient of a ResBlock "
+                     "Conv1d(64,64,3) in one launch -- BN-backward rebuilt and the ReLU mask applied on load, ReLU mask / BN sums / residual add "
+                     "in the epilogue; bf16x6 split products, fp32 accumulate; 31 % of the step's kernel time)",
               peak=BF16X6_PEAK, note=BF16X6_NOTE, pmc=pmc16, pmc_prefixes=("dwgrad64bf_kernel<",))
     return [dw, fwd]
 

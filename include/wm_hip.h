@@ -81,6 +81,10 @@ int wm_resblock_eval_bf(const float* x, const void* w1pb, const void* w2pb, cons
  *   xpro 1, epi 1: x' = relu(x xa + xb) is the weight gradient's input operand; y = data gradient masked by (e1 ea + eb > 0),
  *                  stats [256][2][64] = (sum y, sum y e1) per workgroup (reduce with wm_bn_bwd_finalize)       [conv2 of a block]
  *   xpro 0, epi 2: x as is; y = data gradient + e1; stats NULL                                                 [conv1 of a block]
+ *   xpro 0, epi 8: the second form for a block that FOLLOWS another ResBlock: y = (data gradient + e1) masked by the sign bits of
+ *                  the previous block's output (eb = that mask, passed as const float*), stats = (sum y, sum y ea) with ea = the
+ *                  previous block's pre-BatchNorm activation y2 [B,64,T]: the previous block's ReLU backward and BatchNorm sums
+ *                  ride in this launch's epilogue (it then needs neither wm_relu_bwd_reduce_mask nor a mask of its own); needs gmask.
  * gmask (optional): the sign bits wm_bn_add_relu_mask wrote for the block output.  With it the gradient that reaches the block
  * output is passed as it arrived and masked on load -- as dz in the first form, as e1 in the second -- so the masked copy
  * dz = g (out > 0) never exists in memory (wm_relu_bwd_reduce_mask with dz = NULL supplies the two BatchNorm sums).

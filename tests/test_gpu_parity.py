@@ -389,6 +389,55 @@ def test_resblock_backward_mask_on_load_is_bit_identical(awm, dev, B, T):
         assert torch.equal(res[True][k], res[False][k]), (k, float((res[True][k] - res[False][k]).abs().max()))
 
 
+@pytest.mark.parametrize("B,T", [(2, 128), (3, 704)])
+def test_resblock_pair_fold_matches_two_nodes(awm, dev, B, T):
+    """Two ResBlocks in a row as one tape node (ops.ResBlockPairFn: the second block's conv1 launch, wm_dwgrad64_bf epi 8, also does
+    the first block's ReLU backward and BatchNorm sums) against two ResBlockFn nodes: same forward bits; gradients equal up to the
+    summation order of the first block's two BatchNorm sums (per-workgroup partials instead of per-clip ones)."""
+    if not awm.ops.conv_bf16x6():
+        pytest.skip("fused backward is the bf16x6 build")
+    from awm_amd.modules import resblock_pair
+    sd1, sd2 = _resblock_state(91), _resblock_state(92)
+    x = rnd(B, 64, T, seed=45).abs() * 0.7
+    g = rnd(B, 64, T, seed=46)
+    res, epis = {}, []
+    orig = awm.lib.wm_dwgrad64_bf
+
+    def spy(*a):
+        epis.append(a[20])
+        return orig(*a)
+    awm.lib.wm_dwgrad64_bf = spy
+    try:
+        for on in (True, False):
+            awm.ops.set_pair_fold(on)
+            del epis[:]
+            m1, m2 = awm.ResBlock(64), awm.ResBlock(64)
+            m1.load_state_dict(sd1); m2.load_state_dict(sd2)
+            m1.to(dev).train(); m2.to(dev).train()
+            xd = x.to(dev).requires_grad_()
+            out = resblock_pair(m1, m2, xd)
+            out.backward(g.to(dev))
+            assert epis == ([1, 8, 1, 2] if on else [1, 2, 1, 2]), (on, epis)
+            res[on] = {"out": out.detach().clone(), "dx": xd.grad.clone(),
+                       **{f"1.{k}": p.grad.clone() for k, p in m1.named_parameters()}, **{f"2.{k}": p.grad.clone() for k, p in m2.named_parameters()},
+                       **{f"1.{k}": v.clone() for k, v in m1.state_dict().items() if "running" in k or "tracked" in k}}
+    finally:
+        awm.lib.wm_dwgrad64_bf = orig
+        awm.ops.set_pair_fold(True)
+    assert torch.equal(res[True]["out"], res[False]["out"])
+    wmax = float(res[False]["1.block.0.weight"].abs().max())
+    for k in res[True]:
+        a, b = res[True][k], res[False][k]
+        if not a.is_floating_point() or "running" in k:
+            assert torch.equal(a, b), k
+        elif k.endswith("block.0.bias") or k.endswith("block.3.bias"):
+            assert float(a.abs().max()) <= 1e-3 * wmax + 1e-4 and float(b.abs().max()) <= 1e-3 * wmax + 1e-4     # exactly-zero true gradient
+        elif k.startswith("2."):
+            assert torch.equal(a, b), k                       # the second block's own gradients do not depend on the fold
+        else:
+            check_elementwise(a, b.cpu(), f"pair fold vs two nodes {k}", rtol=2e-5, atol_of_max=5e-6)
+
+
 # ------------------------------------------------------------------------------------------ convT + embedding
 @pytest.mark.parametrize("T", [1000, 1280])      # 1280 = a multiple of 128: the register-resident 7-tap kernel (conv64bf7p); 1000: the ragged-length one
 @pytest.mark.parametrize("with_msg", [True, False])
