@@ -172,8 +172,8 @@ __device__ __forceinline__ void fmac_row16(float (&acc)[4], float H, const float
           "v"(w[16 * J + 6]), "v"(w[16 * J + 7]), "v"(w[16 * J + 8]), "v"(w[16 * J + 9]), "v"(w[16 * J + 10]), "v"(w[16 * J + 11]),
           "v"(w[16 * J + 12]), "v"(w[16 * J + 13]), "v"(w[16 * J + 14]), "v"(w[16 * J + 15]));
 }
-__device__ __forceinline__ float dot64_rowbcast(const float (&H)[4], const float (&w)[64]) {
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+__device__ __forceinline__ float dot64_rowbcast(const float (&H)[4], const float (&w)[64], float init = 0.f) {
+    float acc[4] = {init, 0.f, 0.f, 0.f};
     // a DPP read needs two wait states behind a VALU write of its source (the swaps of rows_replicate); the compiler pads only
     // what it can see, not the inside of an asm statement
     asm volatile("s_nop 1" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
@@ -344,8 +344,14 @@ __global__ __launch_bounds__(256) void lstm_fwd_fused_kernel(const float* __rest
     const float bias = b_ih[n] + b_hh[n];
     if (tid < 128) hsm[tid] = 0.f;
     float c = 0.f;
-    float* gb = SAVE ? gates + (size_t)b * T * 256 + np : nullptr;
-    float* cb = SAVE ? cst + (size_t)b * T * 64 + u : nullptr;
+    // per-step outputs through buffer descriptors: the step index travels as a scalar offset, the lane's part is fixed, lanes that
+    // have nothing to store point past the end of the descriptor (the hardware drops the access): no 64-bit address arithmetic and
+    // no lane mask on the recurrence's critical path
+    const wm_srd_t sgb = make_srd(SAVE ? gates + (size_t)b * T * 256 : hout, SAVE ? (size_t)T * 256 * sizeof(float) : 0);
+    const wm_srd_t scb = make_srd(SAVE ? cst + (size_t)b * T * 64 : hout, SAVE ? (size_t)T * 64 * sizeof(float) : 0);
+    const wm_srd_t shb = make_srd(hout + (size_t)b * 64 * T, (size_t)64 * T * sizeof(float));
+    const unsigned vgb = (unsigned)np * 4u, vcb = (q == 1) ? (unsigned)u * 4u : 0xFFFFFF00u;
+    const unsigned vhb = (unsigned)(u * T + 4 * q) * 4u;
     float* hb = hout + ((size_t)b * 64 + u) * T;
     const bool is_g = (q == 2);
 
@@ -432,8 +438,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_fused_kernel(const float* __rest
                 LSTAMP(ls1, hv);                           // h of the previous step is in registers (LDS read latency)
                 Hh[0] = hv;
                 if (s >= 2 && s < 26) mfma_one(2 * (s - 2) + 1);
-                const float dotp = dot64_rowbcast(Hh, wr);
-                float pre = dotp + xin;
+                float pre = dot64_rowbcast(Hh, wr, xin);     // the projection term rides in as the first accumulator's start value
                 LSTAMP(ls2, pre);                          // 64-term dot product of the lane's gate row done
                 float act = gate_act(pre, is_g);
                 LSTAMP(ls3, act);                          // gate activation (exp + rcp)
@@ -443,12 +448,12 @@ __global__ __launch_bounds__(256) void lstm_fwd_fused_kernel(const float* __rest
                 LSTAMP(ls4, h);                            // quad exchange, cell update, tanh(c)
                 hsm[((s + 1) & 1) * 64 + rowbcast_slot(u)] = h;            // the four lanes of a quad hold the same h: no lane mask
                 if (SAVE) {
-                    gb[(size_t)t * 256] = act;             // one contiguous 256-B segment per wave
-                    if (q == 1) cb[(size_t)t * 64] = c;
+                    buf_store(sgb, act, vgb, (unsigned)t * 1024u);      // one contiguous 256-B segment per wave
+                    buf_store(scb, c, vcb, (unsigned)t * 256u);         // the q == 1 lane of every quad
                 }
                 if (((s >> 2) & 3) == q) hk[s & 3] = h;
                 if ((s & 15) == 15)                        // every lane holds h for steps 4q .. 4q+3 of this 16-step group
-                    *reinterpret_cast<float4*>(hb + t0 + (s - 15) + 4 * q) = make_float4(hk[0], hk[1], hk[2], hk[3]);
+                    buf_store4(shb, f32x4{hk[0], hk[1], hk[2], hk[3]}, vhb, (unsigned)(t0 + (s - 15)) * 4u);
                 LSTAMP(ls5, h);                            // h to LDS, saved activations / outputs issued
                 __syncthreads();
                 LSTAMP(ls6, c);                            // barrier
@@ -494,9 +499,11 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(float* __restrict__ gates
     for (int j = 0; j < 64; ++j) wt[j] = w_hh[((j & 3) * 64 + wave * 16 + (j >> 2)) * 64 + lane];
     if (tid < 512 / 4) reinterpret_cast<float4*>(&part[0][0][0])[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
     float dc = 0.f;
-    float* gb = gates + (size_t)b * T * 256 + np;
-    const float* cb = cst + (size_t)b * T * 64 + u;
-    const float* dhb = dh_out + ((size_t)b * 64 + u) * T;
+    // per-step operands through buffer descriptors (scalar step offset + a fixed lane part): no 64-bit address arithmetic
+    const wm_srd_t sgb = make_srd(gates + (size_t)b * T * 256, (size_t)T * 256 * sizeof(float));
+    const wm_srd_t scb = make_srd(cst + (size_t)b * T * 64, (size_t)T * 64 * sizeof(float));
+    const wm_srd_t sdh = make_srd(dh_out + (size_t)b * 64 * T, (size_t)64 * T * sizeof(float));
+    const unsigned vgb = (unsigned)np * 4u, vcb = (unsigned)u * 4u, vdh = (unsigned)(u * T) * 4u;
 
     constexpr int CH = 8;
     struct Buf { float ga[CH], cc[CH + 1], dh[CH]; };
@@ -507,11 +514,11 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(float* __restrict__ gates
 #pragma unroll
         for (int j = 0; j < CH; ++j) {
             const int t = max(t1 - CH + 1 + j, 0);
-            f.ga[j] = gb[(size_t)t * 256];
-            f.dh[j] = dhb[t];
+            f.ga[j] = buf_load(sgb, vgb, (unsigned)t * 1024u);
+            f.dh[j] = buf_load(sdh, vdh, (unsigned)t * 4u);
         }
 #pragma unroll
-        for (int j = 0; j <= CH; ++j) f.cc[j] = cb[(size_t)max(t1 - CH + j, 0) * 64];
+        for (int j = 0; j <= CH; ++j) f.cc[j] = buf_load(scb, vcb, (unsigned)max(t1 - CH + j, 0) * 256u);
     };
     const bool is0 = q == 0, is1 = q == 1, is2 = q == 2, is3 = q == 3;
     int pb = 0;   // partial buffer parity
@@ -542,7 +549,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(float* __restrict__ gates
                 float da = (is3 ? dht : dct) * M;
                 dc = dct * gf;
                 LSTAMP(ls2, da);                           // quad exchange, tanh(c), gate derivatives
-                gb[(size_t)t * 256] = da;
+                buf_store(sgb, da, vgb, (unsigned)t * 1024u);
                 // lane k's partial dh[k] over the wave's own 64 gate rows: da row-replicated by three half / row swaps, then 64 products
                 // with the DPP row broadcast (no lane reads, no LDS round trip)
                 float Dd[4];
