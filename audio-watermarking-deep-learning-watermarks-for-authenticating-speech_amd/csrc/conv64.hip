@@ -848,6 +848,9 @@ int launch_conv64bf(const Conv64Args& a, hipStream_t stream) {
 #ifndef WM_BF3_MANUAL
 #define WM_BF3_MANUAL 1
 #endif
+#ifndef WM_BF3_PIN_W
+#define WM_BF3_PIN_W 1
+#endif
 #ifndef WM_BF7_PIPE
 #define WM_BF7_PIPE 1        // 7-tap convolution: 1 = register-resident weights, pipelined (T % 128 == 0), 0 = LDS weights, phase-serial
 #endif
@@ -890,7 +893,13 @@ __global__ __launch_bounds__(256) void conv64bf3_kernel(Conv64Args a) {
 #pragma unroll
             for (int p = 0; p < NP; ++p) {
                 const int e = ((p * KW + (s >> 2)) * 64 + 32 * mt + l31) * 64 + 16 * (s & 3) + 8 * half;
-                Wr[s][p] = __builtin_bit_cast(bf16x8, wg[e >> 3]);
+                u32x4 w_ = __builtin_bit_cast(u32x4, wg[e >> 3]);
+#if WM_BF3_PIN_W
+                // pinned to the AGPR half of the register file (the MFMA reads its A operand from there directly); left to the
+                // allocator, the fragments beyond the VGPR budget are copied back (v_accvgpr_read) in front of their k-step
+                asm volatile("" : "+a"(w_));
+#endif
+                Wr[s][p] = __builtin_bit_cast(bf16x8, w_);
             }
     }
     // ---- staging map (fixed per thread): channel pair cp = 8*wave + (lane & 7), time quads q = 8*i + (lane >> 3)
@@ -1049,24 +1058,12 @@ __global__ __launch_bounds__(256) void conv64bf3_kernel(Conv64Args a) {
     // The epilogue of a tile is deferred into the matrix phase of the NEXT tile (accp = its accumulators): the
     // output stores trickle out between MFMAs instead of arriving as one 8-MB burst from all 256 CUs at once.
     f32x16 accp[2];
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) accp[nt][r] = 0.f;
-    // "previous tile" of the first iteration = the first tile itself with pflag = 0: its zero accumulators are
-    // stored (and overwritten one iteration later by the same lanes, in program order) and add nothing to the sums.
+    // "previous tile" of the first iteration = the first tile itself with accumulators that make its epilogue values ZERO (minus
+    // the bias where one is added): they are stored (and overwritten one iteration later by the same lanes, in program order) and
+    // add nothing to the sums -- no flag, no extra multiply per value
     int pb_ = min(tile, ntiles - 1) / tilesPerClip, pt0 = (min(tile, ntiles - 1) % tilesPerClip) * NT;
-    float pflag = 0.f;
+    bool any_tile = false;
     float e1r[E1 ? 32 : 1];
-    const int loff = 4 * half * T + l31;            // per-lane part of every output / e1 address (fits 32 bits: < 8 T)
-    // scalar part: row (r&3) + 8 (r>>2) of this wave's 32 channels, column block nt
-    auto sidx = [&](int nt, int r) { return ((size_t)pb_ * 64 + 32 * mt + (r & 3) + 8 * (r >> 2)) * T + pt0 + 64 * nh + 32 * nt; };
-    if (E1) {
-#pragma unroll
-        for (int j = 0; j < 32; ++j) e1r[j] = 0.f;
-    }
-    // epilogue of value idx = nt * 16 + r of the previous tile; cb/ct0 = the tile being computed now, whose epilogue
-    // operand replaces the consumed one in the same register (it is needed one full iteration from now)
     // per-row epilogue constants of this lane's 16 accumulator rows, in registers: an LDS read inside an epilogue slice stalls
     // the wave for the whole LDS latency in front of the next MFMA
     constexpr bool KB = (EPI == EPI_BIAS || EPI == EPI_BNADDRELU), KE = (EPI == EPI_RELUMASK || EPI == EPI_BNADDRELU);
@@ -1077,7 +1074,27 @@ __global__ __launch_bounds__(256) void conv64bf3_kernel(Conv64Args a) {
         if (KB) kbias[r] = Cs[192 + co];
         if (KE) { kea[r] = Cs[256 + co]; keb[r] = Cs[320 + co]; }
     }
-    auto epi_value = [&](int idx, int cb, int ct0) {
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accp[nt][r] = (EPI == EPI_BIAS) ? -kbias[r] : 0.f;
+    // output / epilogue-operand addressing through buffer descriptors over the wave's 32 channel rows of a clip: per-lane offset
+    // = column, scalar offset = row (sixteen loop-invariant scalars), the column block nt as the immediate -- one instruction per
+    // value instead of a 64-bit scalar add, a 64-bit vector add and the access
+    const unsigned lcol = (unsigned)(4 * half * T + l31) * 4u;
+    unsigned rowT[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) rowT[r] = (unsigned)(((r & 3) + 8 * (r >> 2)) * T) * 4u;
+    auto row_srd = [&](const float* base, int cb) { return make_srd(base + ((size_t)cb * 64 + 32 * mt) * T, (size_t)32 * T * sizeof(float)); };
+    wm_srd_t syp = row_srd(a.y, pb_);                         // output rows of the PREVIOUS tile's clip
+    unsigned vcolp = lcol + (unsigned)(pt0 + 64 * nh) * 4u;
+    if (E1) {
+#pragma unroll
+        for (int j = 0; j < 32; ++j) e1r[j] = 0.f;
+    }
+    // epilogue of value idx = nt * 16 + r of the previous tile; se1c / vcolc = the tile being computed now, whose epilogue
+    // operand replaces the consumed one in the same register (it is needed one full iteration from now)
+    auto epi_value = [&](int idx, bool fetch, const wm_srd_t& se1c, unsigned vcolc) {
         const int nt = idx >> 4, r = idx & 15;
         float v = accp[nt][r];
         float q = 0.f;
@@ -1085,13 +1102,12 @@ __global__ __launch_bounds__(256) void conv64bf3_kernel(Conv64Args a) {
         if (EPI == EPI_RELUMASK) { q = e1r[idx]; v = (fmaf(q, kea[r], keb[r]) > 0.f) ? v : 0.f; }
         if (EPI == EPI_ADD) v += e1r[idx];
         if (EPI == EPI_BNADDRELU) v = fmaxf(e1r[idx] + fmaf(v + kbias[r], kea[r], keb[r]), 0.f);   // = wm_bn_add_relu of the biased conv
-        (a.y + sidx(nt, r))[loff] = v;
-        if (STATS) { s1[r] = fmaf(pflag, v, s1[r]); s2[r] = fmaf(pflag * v, (EPI == EPI_RELUMASK) ? q : v, s2[r]); }
+        buf_store(syp, v, vcolp + 128u * nt, rowT[r]);
+        if (STATS) { s1[r] += v; s2[r] = fmaf(v, (EPI == EPI_RELUMASK) ? q : v, s2[r]); }
 #if WM_BF3_MANUAL
         if (STATS) asm volatile("" : "+v"(s1[r]), "+v"(s2[r]));
 #endif
-        if (E1 && cb >= 0)
-            e1r[idx] = (a.e1 + ((size_t)cb * 64 + 32 * mt + (r & 3) + 8 * (r >> 2)) * T + ct0 + 64 * nh + 32 * nt)[loff];
+        if (E1 && fetch) e1r[idx] = buf_load(se1c, vcolc + 128u * nt, rowT[r]);
     };
     while (tile < tend) {
         STAMP(ts0);
@@ -1099,6 +1115,8 @@ __global__ __launch_bounds__(256) void conv64bf3_kernel(Conv64Args a) {
         const int next = min(tile + tstep, ntiles - 1), next2 = min(tile + 2 * tstep, ntiles - 1);
         const int b = tile / tilesPerClip, t0 = (tile - b * tilesPerClip) * NT;
         const int nt0 = (next % tilesPerClip) * NT;
+        const wm_srd_t se1c = E1 ? row_srd(a.e1, b) : syp;
+        const unsigned vcolc = lcol + (unsigned)(t0 + 64 * nh) * 4u;
         const unsigned short* xcur = Xb0 + buf * XBUF;
         unsigned short* xnxt = Xb0 + (buf ^ 1) * XBUF;
         f32x16 acc[2];
@@ -1132,9 +1150,9 @@ __global__ __launch_bounds__(256) void conv64bf3_kernel(Conv64Args a) {
             if ((k) == 0) load_halo(next2);                                                                                     \
         }                                                                                                                       \
         if (h < 8) {                                                                                                            \
-            if ((k) == 4) epi_value(2 * h, b, t0);                                                                              \
-            if ((k) == 5) epi_value(2 * h + 1, b, t0);                                                                          \
-        } else if ((k) == 4) epi_value(8 + h, b, t0);                                                                           \
+            if ((k) == 4) epi_value(2 * h, true, se1c, vcolc);                                                                              \
+            if ((k) == 5) epi_value(2 * h + 1, true, se1c, vcolc);                                                                          \
+        } else if ((k) == 4) epi_value(8 + h, true, se1c, vcolc);                                                                           \
     }
 #pragma unroll
         for (int h = 0; h < 24; ++h) {
@@ -1190,8 +1208,8 @@ __global__ __launch_bounds__(256) void conv64bf3_kernel(Conv64Args a) {
                 if ((h & 3) == 3) load_combo(next2, h >> 2);          // this combo's registers are free again
             } else if (h == 16) split_halo(xnxt, nt0);
             else if (h == 17) load_halo(next2);
-            if (h < 8) { epi_value(2 * h, b, t0); epi_value(2 * h + 1, b, t0); }
-            else epi_value(8 + h, b, t0);
+            if (h < 8) { epi_value(2 * h, true, se1c, vcolc); epi_value(2 * h + 1, true, se1c, vcolc); }
+            else epi_value(8 + h, true, se1c, vcolc);
             // interleave: after the fragment reads, one MFMA then a handful of the side instructions, six times
             __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
 #pragma unroll
@@ -1218,7 +1236,8 @@ __global__ __launch_bounds__(256) void conv64bf3_kernel(Conv64Args a) {
 #endif
         STAMP(ts1);
         accp[0] = acc[0]; accp[1] = acc[1];
-        pb_ = b; pt0 = t0; pflag = 1.f;
+        pb_ = b; pt0 = t0; any_tile = true;
+        syp = row_srd(a.y, b); vcolp = vcolc;
         STAMP(ts2);
         lds_barrier();
         STAMP(ts3);
@@ -1239,9 +1258,9 @@ __global__ __launch_bounds__(256) void conv64bf3_kernel(Conv64Args a) {
         for (int i = 0; i < 6; ++i) d[i] = tm[i];
     }
 #endif
-    if (pflag != 0.f) {                              // flush: the last tile's epilogue (its operand is already in e1r)
+    if (any_tile) {                                  // flush: the last tile's epilogue (its operand is already in e1r)
 #pragma unroll
-        for (int idx = 0; idx < 32; ++idx) epi_value(idx, -1, 0);
+        for (int idx = 0; idx < 32; ++idx) epi_value(idx, false, syp, 0u);
     }
     if (STATS) {
         float* red = reinterpret_cast<float*>(Xb0);          // [2 column halves][2][64]
