@@ -20,6 +20,13 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/pmc14_$c -- python3 bench.py --model main14b_2 --steps 2 --warmup 1 --no-cpu-baseline > $out/pmc14_$c.json 2> $out/pmc14_$c.err
   echo "main14b_2 $c rc=$?"
 done
+# in-kernel stamps (diagnostic builds, if present): where a dwgrad64bf tile spends its cycles and what clock the chip holds on random /
+# all-zero operands; the per-step budget of the LSTM recurrences
+P="$GRAFT_REPO_ROOT/audio-watermarking-deep-learning-watermarks-for-authenticating-speech_amd"
+if [ -f "$P/libwm_hip_stamp.so" ]; then
+  for m in random zeros random; do echo "== operands: $m"; python3 tests/diag_stamp_dw.py 256 $m 2>&1 | grep -v amdgpu.ids | grep -v "    wave"; done > $out/dwgrad_stamps.txt
+fi
+if [ -f "$P/libwm_lstm_stamp.so" ]; then python3 tests/diag_stamp_lstm.py 256 2>&1 | grep -v amdgpu.ids > $out/lstm_step_budget.txt; fi
 # keep what travels back small: counter CSVs only
 find $out -name "*kernel_trace.csv" -size +20M -delete
 du -sh $out
