@@ -110,7 +110,7 @@ template <bool MASK, bool WRITE>
 __global__ __launch_bounds__(256) void relu_bwd_reduce_kernel(const float* __restrict__ g, const float* __restrict__ out,
                                                               const unsigned* __restrict__ mask,
                                                               const float* __restrict__ y, float* __restrict__ dz,
-                                                              float* __restrict__ partial, int T4) {
+                                                              float* __restrict__ partial, float* __restrict__ dzmax, int T4) {
     __shared__ float scratch[8];
     const int row = blockIdx.x, b = row >> 6, c = row & 63;
     const float4* gr = reinterpret_cast<const float4*>(g) + (size_t)row * T4;
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void relu_bwd_reduce_kernel(const float* __res
     const float4* yr = reinterpret_cast<const float4*>(y) + (size_t)row * T4;
     float4* dr = WRITE ? reinterpret_cast<float4*>(dz) + (size_t)row * T4 : nullptr;
     const unsigned* mrow = MASK ? mask + (size_t)row * ((T4 + 7) >> 3) : nullptr;
-    float s1 = 0.f, s2 = 0.f;
+    float s1 = 0.f, s2 = 0.f, mx = 0.f;
     for (int i = threadIdx.x; i < T4; i += 256) {
         const float4 gg = gr[i], yy = yr[i];
         bool p0, p1, p2, p3;
@@ -135,11 +135,20 @@ __global__ __launch_bounds__(256) void relu_bwd_reduce_kernel(const float* __res
         d.z = p2 ? gg.z : 0.f;
         d.w = p3 ? gg.w : 0.f;
         if (WRITE) dr[i] = d;
+        mx = fmaxf(mx, fmaxf(fmaxf(fabsf(d.x), fabsf(d.y)), fmaxf(fabsf(d.z), fabsf(d.w))));
         s1 += (d.x + d.y) + (d.z + d.w);
         s2 += fmaf(d.x, yy.x, d.y * yy.y) + fmaf(d.z, yy.z, d.w * yy.w);
     }
     s1 = block_sum<4>(s1, scratch);
     s2 = block_sum<4>(s2, scratch + 4);
+    if (dzmax) {                                     // max |dz| of the row: sizes the gradient's scale for the f16-split kernels
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = mx;
+        __syncthreads();
+        if (threadIdx.x == 0) dzmax[row] = fmaxf(fmaxf(scratch[0], scratch[1]), fmaxf(scratch[2], scratch[3]));
+    }
     if (threadIdx.x == 0) {
         partial[(size_t)b * 128 + c] = s1;
         partial[(size_t)b * 128 + 64 + c] = s2;
@@ -150,10 +159,22 @@ __global__ __launch_bounds__(256) void relu_bwd_reduce_kernel(const float* __res
 __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ partials, int nparts, double count,
                                        const float* __restrict__ gamma, const float* __restrict__ save_mean,
                                        const float* __restrict__ save_invstd, float* A, float* Bc, float* Cc,
-                                       float* dgamma, float* dbeta, int accumulate, int eval_mode) {
+                                       float* dgamma, float* dbeta, int accumulate, int eval_mode,
+                                       const float* __restrict__ dzmax, int nmax, float* gscale) {
     __shared__ double red[16][2][64];
+    __shared__ float mred[1024 / 64 + 64];
     double s1, s2;
     reduce_partials_1024(partials, nparts, s1, s2, red);
+    if (gscale) {
+        // max |dz| over the tensor (one entry per producer block): with max |A| it sizes the power-of-two scale that maps the rebuilt
+        // gradient g = A dz + B + C y into the f16 range for the two-piece split (wm_dwgrad64_bf, arith 1)
+        float mx = 0.f;
+        for (int i = threadIdx.x; i < nmax; i += 1024) mx = fmaxf(mx, dzmax[i]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        if ((threadIdx.x & 63) == 0) mred[threadIdx.x >> 6] = mx;
+    }
+    __syncthreads();
     if (threadIdx.x >= 64) return;
     const int c = threadIdx.x;
     const double mu = save_mean[c], is = save_invstd[c], ga = gamma[c];
@@ -171,6 +192,23 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __re
     Bc[64 + c] = (float)(Bd - (double)Bh);
     if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)sxh : (float)sxh;
     if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)s1 : (float)s1;
+    if (gscale) {                                    // threads 0..63 = one wave: max |A| over channels, max |dz| over the blocks
+        float amax = fabsf(Af), mx = 0.f;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
+#pragma unroll
+        for (int i = 0; i < 16; ++i) mx = fmaxf(mx, mred[i]);
+        if (c == 0) {
+            // A dz lands at <= 2^9 = 512: 128 x below the f16 maximum for the B + C y part (the kernel clamps at +-6e4 on top, so a
+            // pathological spike saturates one element instead of producing an infinity), tiny elements keep 2^-33 of the maximum
+            const float big = amax * mx;
+            float gs = 1.f;
+            if (big > 0.f && big < 3.0e38f) gs = exp2f(floorf(log2f(512.f / big)));
+            gs = fminf(fmaxf(gs, 1.0e-30f), 1.0e30f);
+            gscale[0] = gs;
+            gscale[1] = 1.f / gs;
+        }
+    }
 }
 
 }  // namespace
@@ -219,30 +257,33 @@ int wm_bn_add_relu_mask(const float* x, const float* y2, const float* scale, con
 int wm_relu_bwd_reduce(const float* g, const float* out, const float* y2, float* dz, float* partial, int B, int T,
                        hipStream_t stream) {
     if (T & 3) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL((relu_bwd_reduce_kernel<false, true>), dim3(B * 64), dim3(256), 0, stream, g, out, (const unsigned*)nullptr, y2, dz, partial, T / 4);
+    hipLaunchKernelGGL((relu_bwd_reduce_kernel<false, true>), dim3(B * 64), dim3(256), 0, stream, g, out, (const unsigned*)nullptr, y2, dz, partial,
+                       (float*)nullptr, T / 4);
     WM_CHECK_LAUNCH();
     return 0;
 }
 
 // The same from the sign bits; dz == NULL: only the two sums (the consumer masks g itself: wm_dwgrad64_bf's gmask).
-int wm_relu_bwd_reduce_mask(const float* g, const void* mask, const float* y2, float* dz, float* partial, int B, int T,
+// dzmax (optional, B * 64 floats): max |dz| of every row, for wm_bn_bwd_finalize's gradient scale.
+int wm_relu_bwd_reduce_mask(const float* g, const void* mask, const float* y2, float* dz, float* partial, float* dzmax, int B, int T,
                             hipStream_t stream) {
     if ((T & 3) || !mask) return (int)hipErrorInvalidValue;
     if (dz)
         hipLaunchKernelGGL((relu_bwd_reduce_kernel<true, true>), dim3(B * 64), dim3(256), 0, stream, g, (const float*)nullptr,
-                           reinterpret_cast<const unsigned*>(mask), y2, dz, partial, T / 4);
+                           reinterpret_cast<const unsigned*>(mask), y2, dz, partial, dzmax, T / 4);
     else
         hipLaunchKernelGGL((relu_bwd_reduce_kernel<true, false>), dim3(B * 64), dim3(256), 0, stream, g, (const float*)nullptr,
-                           reinterpret_cast<const unsigned*>(mask), y2, (float*)nullptr, partial, T / 4);
+                           reinterpret_cast<const unsigned*>(mask), y2, (float*)nullptr, partial, dzmax, T / 4);
     WM_CHECK_LAUNCH();
     return 0;
 }
 
 int wm_bn_bwd_finalize(const float* partials, int nparts, double count, const float* gamma, const float* save_mean,
                        const float* save_invstd, float* A, float* Bc, float* Cc, float* dgamma, float* dbeta,
-                       int accumulate, int eval_mode, hipStream_t stream) {
+                       int accumulate, int eval_mode, const float* dzmax, int nmax, float* gscale, hipStream_t stream) {
+    if (gscale && (!dzmax || nmax <= 0)) return (int)hipErrorInvalidValue;
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(1024), 0, stream, partials, nparts, count, gamma, save_mean,
-                       save_invstd, A, Bc, Cc, dgamma, dbeta, accumulate, eval_mode);
+                       save_invstd, A, Bc, Cc, dgamma, dbeta, accumulate, eval_mode, dzmax, nmax, gscale);
     WM_CHECK_LAUNCH();
     return 0;
 }

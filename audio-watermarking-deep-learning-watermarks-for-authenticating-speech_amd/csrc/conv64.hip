@@ -14,6 +14,9 @@
 //   D tile (cout x time) leaves the accumulators as 128-B row segments (time is contiguous).
 #include "wm_common.hpp"
 using namespace wm;
+typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #ifdef WM_STAMP
 // diagnostic build only (-DWM_STAMP): per-wave cycle totals of the kernel's phases
@@ -2926,6 +2929,39 @@ int launch_wgrad64bf7(const Wgrad64Args& a, int* grid_out, hipStream_t stream) {
     return 0;
 }
 
+// f16 two-piece image of a k3 weight for dwgrad64bf_kernel<..., H = true>: [2 pieces][3 taps][64 out][64 in] f16 of w * ws, ws = the power
+// of two that brings max |w| to [2^9, 2^10), followed by {ws, 1 / ws} as two floats.  One workgroup (12 288 values).
+__global__ __launch_bounds__(1024) void pack_w64_h_kernel(const float* __restrict__ w, unsigned short* __restrict__ wph, int mode) {
+    __shared__ float red[16];
+    __shared__ float sc;
+    float mx = 0.f;
+    for (int i = threadIdx.x; i < 3 * 4096; i += 1024) mx = fmaxf(mx, fabsf(w[i]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float m = 0.f;
+        for (int i = 0; i < 16; ++i) m = fmaxf(m, red[i]);
+        float ws = 1.f;
+        if (m > 0.f && m < 3.0e38f) ws = exp2f(floorf(log2f(1023.f / m)));
+        ws = fminf(fmaxf(ws, 1.0e-30f), 1.0e30f);
+        sc = ws;
+        float* tail = reinterpret_cast<float*>(wph + 2 * 3 * 4096);
+        tail[0] = ws; tail[1] = 1.f / ws;
+    }
+    __syncthreads();
+    const float ws = sc;
+    for (int i = threadIdx.x; i < 3 * 4096; i += 1024) {
+        const int tap = i / 4096, out = (i / 64) % 64, in = i % 64;
+        const float v = ((mode == 0) ? w[(out * 64 + in) * 3 + tap] : w[(in * 64 + out) * 3 + (2 - tap)]) * ws;
+        const _Float16 hi = (_Float16)v;
+        const _Float16 lo = (_Float16)(v - (float)hi);
+        wph[i] = __builtin_bit_cast(unsigned short, hi);
+        wph[3 * 4096 + i] = __builtin_bit_cast(unsigned short, lo);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Data gradient AND weight gradient of a k3 convolution in ONE launch (ResBlock backward, py/main16.py:112-125 under
 // autograd).  Both read the same gradient frames (dz, and y for the BatchNorm-backward rebuild g = A dz + B + C y): as two
@@ -2957,12 +2993,22 @@ struct DWArgs {
                                                         // [row][t / 32]): applied to g (conv2 pair) / to e1 (conv1 pair) on load
     const unsigned* pmask; const float* py2;            // EPI_ADDSTATS: sign bits / pre-BatchNorm activation y2 of the block BEFORE this
                                                         // one: y = (data gradient + e1) masked, stats = (sum y, sum y py2)
+    const float* gscale;                                // H (f16 two-piece split): {gs, 1 / gs}, the power-of-two scale of the rebuilt
+                                                        // gradient (wm_bn_bwd_finalize); the weight image carries its own scale
+    float* dzmax;                                       // H, STATS forms: max |y| per workgroup [grid] (sizes the NEXT launch's scale)
 };
 
-template <int EPI, int XPRO, bool GM>
+// H = false: bf16 three-piece split, six piece products per product (bf16x6).  H = true: f16 TWO-piece split (hi = RNE_f16(x s),
+// lo = RNE_f16(x s - hi): 22 bits), three products hi hi + hi lo + lo hi on v_mfma_f32_32x32x16_f16 -- half the matrix work, two
+// thirds of the split / LDS work.  The f16 range is met by power-of-two scales: the weights' (chosen by the pack kernel from
+// max |w|, stored behind the image), the gradient's (gs from wm_bn_bwd_finalize: max |A| max |dz| -> 2^9, applied through the
+// BatchNorm-backward constants, i.e. for free; the rebuilt value is clamped to +-6e4 so that a pathological element saturates
+// instead of becoming an infinity); activations need none.  Results are unscaled in the epilogue / at the slab write.
+template <int EPI, int XPRO, bool GM, bool H>
 __global__ __launch_bounds__(256) void dwgrad64bf_kernel(DWArgs a) {
     static_assert((EPI == EPI_RELUMASK && XPRO == PRO_BNRELU) || ((EPI == EPI_ADD || EPI == EPI_ADDSTATS) && XPRO == PRO_NONE), "conv2 pair or conv1 pair");
-    constexpr int KW = 3, NT = 64, NP = 3, ROWS = NT + 2, PITCH = 72, PG = 72, PX = 88, XO = 8;
+    constexpr int KW = 3, NT = 64, NP = H ? 2 : 3, ROWS = NT + 2, PITCH = 72, PG = 72, PX = 88, XO = 8;
+    constexpr int NPR = H ? 3 : 6, SPM = 6 / NPR;          // piece products per product; side-work slices per MFMA
     constexpr bool STATS = (EPI == EPI_RELUMASK || EPI == EPI_ADDSTATS);
     constexpr bool FOLD = (EPI == EPI_ADDSTATS);          // conv1 pair that also does the previous block's ReLU backward + BN sums
     constexpr int DIMG = NP * ROWS * PITCH, GIMG = NP * 64 * PG, XIMG = NP * 64 * PX;
@@ -2978,7 +3024,11 @@ __global__ __launch_bounds__(256) void dwgrad64bf_kernel(DWArgs a) {
     const int tilesPerClip = T / NT, ntiles = a.B * tilesPerClip;
 
     // ---- resident data-gradient weight fragments
-    bf16x8 Wr[12][NP];
+    u32x4 Wr[12][NP];
+    // H: {ws, 1 / ws} behind the [NP][KW][64][64] image
+    const float winv = H ? reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(a.wp) + NP * KW * 4096)[1] : 1.f;
+    const float gs = H ? a.gscale[0] : 1.f, ginv = H ? a.gscale[1] : 1.f;
+    const float dinv = ginv * winv;                        // data gradient: (g gs) (w ws) -> g w
     {
         const uint4* wg = reinterpret_cast<const uint4*>(a.wp);
 #pragma unroll
@@ -2990,7 +3040,7 @@ __global__ __launch_bounds__(256) void dwgrad64bf_kernel(DWArgs a) {
                 // pinned to the AGPR half of the register file: the MFMA reads its A operand from there directly.  Left to the
                 // allocator the fragments are SPILLED to AGPRs and copied back (v_accvgpr_read) in front of every k-step.
                 asm volatile("" : "+a"(w_));
-                Wr[s][p] = __builtin_bit_cast(bf16x8, w_);
+                Wr[s][p] = w_;
             }
     }
     // ---- staging map: channel pair cp (channels c0, c0 + 1), unit u = time quad q0 + 8 u; halo: channel hc, side hh
@@ -3096,10 +3146,10 @@ __global__ __launch_bounds__(256) void dwgrad64bf_kernel(DWArgs a) {
     float kga[2], kgb[2], kgc[2], kgl[2], kxa[2], kxb[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        kga[j] = Cs[c0 + j]; kgb[j] = Cs[64 + c0 + j]; kgc[j] = Cs[128 + c0 + j]; kgl[j] = Cs[192 + c0 + j];
+        kga[j] = Cs[c0 + j] * gs; kgb[j] = Cs[64 + c0 + j] * gs; kgc[j] = Cs[128 + c0 + j] * gs; kgl[j] = Cs[192 + c0 + j] * gs;   // gs = 1 | 2^k: exact
         kxa[j] = Cs[256 + c0 + j]; kxb[j] = Cs[320 + c0 + j];
     }
-    const float hga = Cs[hc], hgb = Cs[64 + hc], hgc = Cs[128 + hc], hgl = Cs[192 + hc], hxa = Cs[256 + hc], hxb = Cs[320 + hc];
+    const float hga = Cs[hc] * gs, hgb = Cs[64 + hc] * gs, hgc = Cs[128 + hc] * gs, hgl = Cs[192 + hc] * gs, hxa = Cs[256 + hc], hxb = Cs[320 + hc];
 
     // ---- split stages on a value pair (va, vb) -> pieces (p0, p1, [lo]) and a second pair (vc, vd) -> (q0_, q1_, [lo])
     float va = 0.f, vb = 0.f, vc = 0.f, vd = 0.f;
@@ -3107,36 +3157,54 @@ __global__ __launch_bounds__(256) void dwgrad64bf_kernel(DWArgs a) {
     float bsum[2] = {0.f, 0.f};
     float bflag = 1.f;
     auto s1a = [&]() {
-        const bf16x2 h_ = {(__bf16)va, (__bf16)vb};
-        p0 = __builtin_bit_cast(unsigned, h_);
-        va -= __uint_as_float(p0 << 16); vb -= __uint_as_float(p0 & 0xffff0000u);
+        if (H) {
+            const h16x2 h_ = __builtin_convertvector(f32x2{va, vb}, h16x2);
+            p0 = __builtin_bit_cast(unsigned, h_);
+            va -= (float)h_.x; vb -= (float)h_.y;
+        } else {
+            const bf16x2 h_ = {(__bf16)va, (__bf16)vb};
+            p0 = __builtin_bit_cast(unsigned, h_);
+            va -= __uint_as_float(p0 << 16); vb -= __uint_as_float(p0 & 0xffff0000u);
+        }
         asm volatile("" : "+v"(va), "+v"(vb), "+v"(p0));
     };
     auto s2a = [&]() {
+        if (H) return;                                   // two pieces: no middle one
         const bf16x2 m_ = {(__bf16)va, (__bf16)vb};
         p1 = __builtin_bit_cast(unsigned, m_);
         va -= __uint_as_float(p1 << 16); vb -= __uint_as_float(p1 & 0xffff0000u);
         asm volatile("" : "+v"(va), "+v"(vb), "+v"(p1));
     };
     auto s1b = [&]() {
-        const bf16x2 h_ = {(__bf16)vc, (__bf16)vd};
-        r0 = __builtin_bit_cast(unsigned, h_);
-        vc -= __uint_as_float(r0 << 16); vd -= __uint_as_float(r0 & 0xffff0000u);
+        if (H) {
+            const h16x2 h_ = __builtin_convertvector(f32x2{vc, vd}, h16x2);
+            r0 = __builtin_bit_cast(unsigned, h_);
+            vc -= (float)h_.x; vd -= (float)h_.y;
+        } else {
+            const bf16x2 h_ = {(__bf16)vc, (__bf16)vd};
+            r0 = __builtin_bit_cast(unsigned, h_);
+            vc -= __uint_as_float(r0 << 16); vd -= __uint_as_float(r0 & 0xffff0000u);
+        }
         asm volatile("" : "+v"(vc), "+v"(vd), "+v"(r0));
     };
     auto s2b = [&]() {
+        if (H) return;
         const bf16x2 m_ = {(__bf16)vc, (__bf16)vd};
         r1 = __builtin_bit_cast(unsigned, m_);
         vc -= __uint_as_float(r1 << 16); vd -= __uint_as_float(r1 & 0xffff0000u);
         asm volatile("" : "+v"(vc), "+v"(vd), "+v"(r1));
     };
     unsigned l0 = 0, l1 = 0;
+    auto lo_pair = [&](float x0, float x1) -> unsigned {         // the last piece of a value pair
+        if (H) return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{x0, x1}, h16x2));
+        const bf16x2 l_ = {(__bf16)x0, (__bf16)x1};
+        return __builtin_bit_cast(unsigned, l_);
+    };
     auto out4 = [&](unsigned short* dst, int stride_p) {         // two time pairs of one channel row: 8-byte writes
-        const bf16x2 la = {(__bf16)va, (__bf16)vb}, lb = {(__bf16)vc, (__bf16)vd};
-        l0 = __builtin_bit_cast(unsigned, la); l1 = __builtin_bit_cast(unsigned, lb);
+        l0 = lo_pair(va, vb); l1 = lo_pair(vc, vd);
         *reinterpret_cast<uint2*>(dst) = make_uint2(p0, r0);
-        *reinterpret_cast<uint2*>(dst + stride_p) = make_uint2(p1, r1);
-        *reinterpret_cast<uint2*>(dst + 2 * stride_p) = make_uint2(l0, l1);
+        if (!H) *reinterpret_cast<uint2*>(dst + stride_p) = make_uint2(p1, r1);
+        *reinterpret_cast<uint2*>(dst + (NP - 1) * stride_p) = make_uint2(l0, l1);
     };
     // gradient rebuild of channel j of unit u from the raw staging registers (free for the refill afterwards): one value per slice
     // (a slice must stay within the shadow of one MFMA, about seven instructions: a twelve-instruction slice costs its excess in full)
@@ -3150,6 +3218,7 @@ __global__ __launch_bounds__(256) void dwgrad64bf_kernel(DWArgs a) {
             d = __uint_as_float(__float_as_uint(d) & (unsigned)__builtin_amdgcn_sbfe((int)mk_[u][j], e, 1));
         }
         float v = pro_apply<PRO_BNBWD>(d, yv, kga[j], kgb[j], kgc[j], kgl[j]);
+        if (H) v = __builtin_amdgcn_fmed3f(v, -6.0e4f, 6.0e4f);      // a spike saturates; it never becomes an f16 infinity
         bsum[j] = fmaf(bflag, v, bsum[j]);
         asm volatile("" : "+v"(v), "+v"(bsum[j]));
         if (e == 0) gz.x = v; else if (e == 1) gz.y = v; else if (e == 2) gz.z = v; else gz.w = v;
@@ -3178,7 +3247,9 @@ __global__ __launch_bounds__(256) void dwgrad64bf_kernel(DWArgs a) {
         const unsigned d2 = __builtin_amdgcn_perm(gp_[u][1][4 + pr], gp_[u][0][4 + pr], sel);
         unsigned* D32 = reinterpret_cast<unsigned*>(Db);
         const int o = (1 + 4 * (q0 + 8 * u) + e) * (PITCH / 2) + cp;
-        D32[o] = d0; D32[(ROWS * PITCH >> 1) + o] = d1; D32[2 * (ROWS * PITCH >> 1) + o] = d2;
+        D32[o] = d0;
+        if (!H) D32[(ROWS * PITCH >> 1) + o] = d1;
+        D32[(NP - 1) * (ROWS * PITCH >> 1) + o] = d2;
     };
     // halos: the gradient's for image D (rows 0 and 65), the input operand's for image X' (elements XO - 1, XO + 64)
     auto hx_pick = [&]() {
@@ -3188,24 +3259,29 @@ __global__ __launch_bounds__(256) void dwgrad64bf_kernel(DWArgs a) {
         asm volatile("" : "+v"(va), "+v"(vb));
     };
     auto hx_out = [&](unsigned short* X) {
-        const bf16x2 la = {(__bf16)va, (__bf16)vb};
+        const unsigned la = lo_pair(va, vb);
         if (tid < 128) {
             const int o = hc * PX + (hh ? XO + NT : XO - 1);
-            X[o] = (unsigned short)p0; X[64 * PX + o] = (unsigned short)p1; X[2 * 64 * PX + o] = (unsigned short)__builtin_bit_cast(unsigned, la);
+            X[o] = (unsigned short)p0;
+            if (!H) X[64 * PX + o] = (unsigned short)p1;
+            X[(NP - 1) * 64 * PX + o] = (unsigned short)la;
         }
     };
     auto hg_pick = [&]() {
         float hgm = hg;
         if (GMG) hgm = __uint_as_float(__float_as_uint(hg) & (unsigned)__builtin_amdgcn_sbfe((int)(hmk >> hsh_cur), 0, 1));
-        const float v = pro_apply<PRO_BNBWD>(hgm, hy, hga, hgb, hgc, hgl);
+        float v = pro_apply<PRO_BNBWD>(hgm, hy, hga, hgb, hgc, hgl);
+        if (H) v = __builtin_amdgcn_fmed3f(v, -6.0e4f, 6.0e4f);
         va = okh_cur ? v : 0.f; vb = 0.f;
         asm volatile("" : "+v"(va), "+v"(vb));
     };
     auto hg_out = [&]() {
-        const bf16x2 la = {(__bf16)va, (__bf16)vb};
+        const unsigned la = lo_pair(va, vb);
         if (tid < 128) {
             const int o = (hh ? NT + 1 : 0) * PITCH + hc;
-            Db[o] = (unsigned short)p0; Db[ROWS * PITCH + o] = (unsigned short)p1; Db[2 * ROWS * PITCH + o] = (unsigned short)__builtin_bit_cast(unsigned, la);
+            Db[o] = (unsigned short)p0;
+            if (!H) Db[ROWS * PITCH + o] = (unsigned short)p1;
+            Db[(NP - 1) * ROWS * PITCH + o] = (unsigned short)la;
         }
     };
     // phase-A side work, slice v of 64 (the other 8 slices fetch the epilogue operand): the operands in the registers -> images G', X'
@@ -3282,22 +3358,46 @@ __global__ __launch_bounds__(256) void dwgrad64bf_kernel(DWArgs a) {
     // time in the accumulator layout.  Fetched one tile AHEAD (e1n, for the next tile, while this one is in phase A) it follows
     // the staging loads of the same tile by less than one tile's worth of traffic and is served by the XCD's L2 instead of HBM
     // (fetched as late as the tile needs it, 32 % of the kernel's HBM traffic was this re-read).
-    constexpr bool EAHEAD = (EPI == EPI_RELUMASK);
-    f32x4 e1n[EAHEAD ? 4 : 1];
-    unsigned emk = 0u, pmk = 0u;
-    f32x4 pyq[FOLD ? 4 : 1];
+    // (round 3, f16 build: with half the MFMAs per phase an operand fetched in phase A no longer has a phase's worth of time to arrive
+    // before the epilogue in phase B needs it -- EVERY epilogue operand of every form is now fetched one tile ahead: e1, the mask words,
+    // the previous block's y2)
+    constexpr bool EAHEAD = true;
+    f32x4 e1n[4];
+    unsigned emk = 0u, pmk = 0u, emkn = 0u, pmkn = 0u;
+    f32x4 pyq[FOLD ? 4 : 1], pyn[FOLD ? 4 : 1];
     const float kea = (EPI == EPI_RELUMASK) ? Cs[384 + 32 * mt + l31] : 0.f, keb = (EPI == EPI_RELUMASK) ? Cs[448 + 32 * mt + l31] : 0.f;
     int buf = 0;
 #ifdef WM_STAMP
     unsigned long long tm[6] = {0, 0, 0, 0, 0, 0};
 #endif
-    if (EAHEAD) {                                        // the first tile's epilogue operand
+    {                                                    // the first tile's epilogue operands
         const int b0 = tile / tilesPerClip, t00 = (tile - b0 * tilesPerClip) * NT;
-        const wm_srd_t s0 = make_srd(a.e1 + ((size_t)b0 * 64 + 32 * mt) * T, (size_t)32 * T * sizeof(float));
+        const size_t slab0 = ((size_t)b0 * 64 + 32 * mt) * T;
+        const unsigned eo0 = (unsigned)(l31 * T + t00 + 32 * nh + 4 * half) * 4u, mo0 = ((unsigned)l31 * nwm + ((unsigned)t00 >> 5) + (unsigned)nh) * 4u;
+        const wm_srd_t s0 = make_srd(a.e1 + slab0, (size_t)32 * T * sizeof(float));
 #pragma unroll
-        for (int q4 = 0; q4 < 4; ++q4) e1q[q4] = buf_load4(s0, (unsigned)(l31 * T + t00 + 32 * nh + 4 * half) * 4u + 32u * q4, 0u);
+        for (int q4 = 0; q4 < 4; ++q4) e1q[q4] = buf_load4(s0, eo0 + 32u * q4, 0u);
+        if (GM && (EPI == EPI_ADD || EPI == EPI_ADDSTATS))
+            emk = __builtin_bit_cast(unsigned, buf_load(make_srd(reinterpret_cast<const float*>(a.gmask) + ((size_t)b0 * 64 + 32 * mt) * nwm,
+                                                                 (size_t)32 * nwm * sizeof(unsigned)), mo0, 0u));
+        if (FOLD) {
+            pmk = __builtin_bit_cast(unsigned, buf_load(make_srd(reinterpret_cast<const float*>(a.pmask) + ((size_t)b0 * 64 + 32 * mt) * nwm,
+                                                                 (size_t)32 * nwm * sizeof(unsigned)), mo0, 0u));
+            const wm_srd_t sp0 = make_srd(a.py2 + slab0, (size_t)32 * T * sizeof(float));
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) pyq[q4] = buf_load4(sp0, eo0 + 32u * q4, 0u);
+        }
     }
 #define FENCE __builtin_amdgcn_sched_barrier(0)
+    // one piece product on raw 128-bit fragments; the j-th product of a k-step pairs piece PA(j) of the first operand with piece PB(j)
+    // of the second, small terms first (bf16x6: mid mid, hi lo, lo hi, hi mid, mid hi, hi hi; f16: lo hi, hi lo, hi hi)
+    auto mma = [&](const u32x4& A_, const u32x4& B_, f32x16 c) -> f32x16 {
+        if (H) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, A_), __builtin_bit_cast(h16x8, B_), c, 0, 0, 0);
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A_), __builtin_bit_cast(bf16x8, B_), c, 0, 0, 0);
+    };
+    auto PA = [](int j) { return H ? (j == 0 ? 1 : 0) : ((j == 0 || j == 4) ? 1 : (j == 2 ? 2 : 0)); };
+    auto PB = [](int j) { return H ? (j == 1 ? 1 : 0) : ((j == 0 || j == 3) ? 1 : (j == 1 ? 2 : 0)); };
+    float vmax = 0.f;                                    // H: running max |y| of the data-gradient values this lane stores
     while (tile < ntiles) {
         // registers: the raw operands of tile + tstep (clamped: the duplicate of the last tile is split but never used)
         const int b = tile / tilesPerClip, t0 = (tile - b * tilesPerClip) * NT;
@@ -3324,7 +3424,13 @@ __global__ __launch_bounds__(256) void dwgrad64bf_kernel(DWArgs a) {
         const wm_srd_t spy = FOLD ? make_srd(a.py2 + slab, (size_t)32 * T * sizeof(float)) : se1;
         const wm_srd_t sme = GME ? make_srd(reinterpret_cast<const float*>(a.gmask) + ((size_t)b * 64 + 32 * mt) * nwm,
                                             (size_t)32 * nwm * sizeof(unsigned)) : se1;
-        const unsigned emoff = ((unsigned)l31 * nwm + ((unsigned)t0 >> 5) + (unsigned)nh) * 4u;
+        const size_t slabn = ((size_t)bnx * 64 + 32 * mt) * T;
+        const wm_srd_t spmn = FOLD ? make_srd(reinterpret_cast<const float*>(a.pmask) + ((size_t)bnx * 64 + 32 * mt) * nwm,
+                                              (size_t)32 * nwm * sizeof(unsigned)) : se1;
+        const wm_srd_t spyn = FOLD ? make_srd(a.py2 + slabn, (size_t)32 * T * sizeof(float)) : se1;
+        const wm_srd_t smen = GME ? make_srd(reinterpret_cast<const float*>(a.gmask) + ((size_t)bnx * 64 + 32 * mt) * nwm,
+                                             (size_t)32 * nwm * sizeof(unsigned)) : se1;
+        const unsigned emoffn = ((unsigned)l31 * nwm + ((unsigned)t0nx >> 5) + (unsigned)nh) * 4u;
 
         STAMP(ts0);
         // ---------------- phase A: data gradient out of image D
@@ -3333,34 +3439,37 @@ __global__ __launch_bounds__(256) void dwgrad64bf_kernel(DWArgs a) {
         for (int r = 0; r < 16; ++r) dacc[r] = 0.f;
         {
             const unsigned short* drow = Db + (32 * nh + l31) * PITCH + 8 * half;
-            bf16x8 Bq[2][NP];
+            u32x4 Bq[2][NP];
 #pragma unroll
-            for (int p = 0; p < NP; ++p) Bq[0][p] = *reinterpret_cast<const bf16x8*>(drow + p * ROWS * PITCH);
+            for (int p = 0; p < NP; ++p) Bq[0][p] = *reinterpret_cast<const u32x4*>(drow + p * ROWS * PITCH);
 #pragma unroll
             for (int s = 0; s < 12; ++s) {
                 if (s + 1 < 12) {
 #pragma unroll
                     for (int p = 0; p < NP; ++p)
-                        Bq[(s + 1) & 1][p] = *reinterpret_cast<const bf16x8*>(drow + (p * ROWS + ((s + 1) >> 2)) * PITCH + 16 * ((s + 1) & 3));
+                        Bq[(s + 1) & 1][p] = *reinterpret_cast<const u32x4*>(drow + (p * ROWS + ((s + 1) >> 2)) * PITCH + 16 * ((s + 1) & 3));
                 }
-                const bf16x8* Bf = Bq[s & 1];
+                const u32x4* Bf = Bq[s & 1];
                 // the weight-gradient accumulators stay where they are across this phase: left alone, the allocator lends a[0:15] of
                 // one of them to dacc and copies it out and back around every phase A (32 v_accvgpr moves per tile)
                 if ((s & 3) == 1) asm volatile("" : "+a"(wacc[0]), "+a"(wacc[1]), "+a"(wacc[2]));
 #pragma unroll
-                for (int j = 0; j < 6; ++j) {
-                    const int pa = (j == 0 || j == 4) ? 1 : (j == 2 ? 2 : 0), pb = (j == 0 || j == 3) ? 1 : (j == 1 ? 2 : 0);
+                for (int j = 0; j < NPR; ++j) {
                     FENCE;
-                    dacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Bf[pb], Wr[s][pa], dacc, 0, 0, 0);      // D^T: rows = time, columns = channel
+                    dacc = mma(Bf[PB(j)], Wr[s][PA(j)], dacc);      // D^T: rows = time, columns = channel (gradient piece PB, weight piece PA)
                     FENCE;
-                    const int m = s * 6 + j;                         // 0..71
-                    if (m < NSA) { sideA(m, Gn, Xn); refillA(m); }
-                    else if (((m - NSA) & 1) == 0) {
-                        if (EAHEAD) e1n[(m - NSA) >> 1] = buf_load4(se1n, eoffn + 32u * ((m - NSA) >> 1), 0u);
-                        else e1q[(m - NSA) >> 1] = buf_load4(se1, eoff + 32u * ((m - NSA) >> 1), 0u);
+                    // SPM slices of side work behind this MFMA (72 slices per phase whatever the arithmetic)
+#pragma unroll
+                    for (int i_ = 0; i_ < SPM; ++i_) {
+                        const int m = (s * NPR + j) * SPM + i_;          // 0..71
+                        if (m < NSA) {
+                            sideA(m, Gn, Xn); refillA(m);
+                            if (GME && m == 61) emkn = __builtin_bit_cast(unsigned, buf_load(smen, emoffn, 0u));
+                            if (FOLD && m == 62) pmkn = __builtin_bit_cast(unsigned, buf_load(spmn, emoffn, 0u));
+                        }
+                        else if (((m - NSA) & 1) == 0) e1n[(m - NSA) >> 1] = buf_load4(se1n, eoffn + 32u * ((m - NSA) >> 1), 0u);
+                        else if (FOLD) pyn[(m - NSA) >> 1] = buf_load4(spyn, eoffn + 32u * ((m - NSA) >> 1), 0u);
                     }
-                    else if (GME && m == NSA + 1) emk = __builtin_bit_cast(unsigned, buf_load(sme, emoff, 0u));
-                    else if (FOLD && m == NSA + 3) pmk = __builtin_bit_cast(unsigned, buf_load(spm, emoff, 0u));
                     FENCE;
                 }
             }
@@ -3377,14 +3486,14 @@ __global__ __launch_bounds__(256) void dwgrad64bf_kernel(DWArgs a) {
         // ---------------- phase B: weight gradient out of images G', X'; image D of the next tile, epilogue of this one
         {
             const int e0 = 8 * half;
-            bf16x8 A[2][NP];
+            u32x4 A[2][NP];
             uint4 f[2][NP];
             unsigned Lw[2][NP], Rw[2][NP];
-            bf16x8 Bl[NP], Br[NP];
+            u32x4 Bl[NP], Br[NP];
             auto read_kb = [&](int kb, int set) {
 #pragma unroll
                 for (int p = 0; p < NP; ++p) {
-                    A[set][p] = *reinterpret_cast<const bf16x8*>(Gc + (p * 64 + mt * 32 + l31) * PG + kb * 16 + e0);
+                    A[set][p] = *reinterpret_cast<const u32x4*>(Gc + (p * 64 + mt * 32 + l31) * PG + kb * 16 + e0);
                     const unsigned short* xr = Xc + (p * 64 + nh * 32 + l31) * PX + XO + kb * 16 + e0;
                     f[set][p] = *reinterpret_cast<const uint4*>(xr);
                     Lw[set][p] = *reinterpret_cast<const unsigned*>(xr - 2);
@@ -3396,20 +3505,21 @@ __global__ __launch_bounds__(256) void dwgrad64bf_kernel(DWArgs a) {
                 uint4 s_ = make_uint4(__builtin_amdgcn_alignbit(g.x, Lw[set][p], 16), __builtin_amdgcn_alignbit(g.y, g.x, 16),
                                       __builtin_amdgcn_alignbit(g.z, g.y, 16), __builtin_amdgcn_alignbit(g.w, g.z, 16));
                 asm volatile("" : "+v"(s_.x), "+v"(s_.y), "+v"(s_.z), "+v"(s_.w));
-                Bl[p] = __builtin_bit_cast(bf16x8, s_);
+                Bl[p] = __builtin_bit_cast(u32x4, s_);
             };
             auto shr = [&](int set, int p) {
                 const uint4 g = f[set][p];
                 uint4 s_ = make_uint4(__builtin_amdgcn_alignbit(g.y, g.x, 16), __builtin_amdgcn_alignbit(g.z, g.y, 16),
                                       __builtin_amdgcn_alignbit(g.w, g.z, 16), __builtin_amdgcn_alignbit(Rw[set][p], g.w, 16));
                 asm volatile("" : "+v"(s_.x), "+v"(s_.y), "+v"(s_.z), "+v"(s_.w));
-                Br[p] = __builtin_bit_cast(bf16x8, s_);
+                Br[p] = __builtin_bit_cast(u32x4, s_);
             };
             // epilogue of accumulator registers 2 i, 2 i + 1 of the data gradient (two time steps of the lane's channel); every second
             // call completes a quad and stores it
             auto epi2 = [&](int i) {
                 const int r0 = 2 * i, r1 = 2 * i + 1;
                 float v0 = dacc[r0], v1 = dacc[r1];
+                if (H) { v0 *= dinv; v1 *= dinv; }                // undo the gradient's and the weights' scales (a power of two: exact)
                 const float q0_ = e1q[r0 >> 2][r0 & 3], q1_ = e1q[r1 >> 2][r1 & 3];
                 if (EPI == EPI_RELUMASK) {
                     // both compares first, both selects after: a select right behind its compare costs two wait states
@@ -3437,45 +3547,52 @@ __global__ __launch_bounds__(256) void dwgrad64bf_kernel(DWArgs a) {
                     asm volatile("" : "+v"(s1), "+v"(s2));
                 }
                 dacc[r0] = v0; dacc[r1] = v1;
+                if (H && STATS) vmax = fmaxf(vmax, fmaxf(fabsf(v0), fabsf(v1)));
                 if (i & 1) {
                     const int q4 = i >> 1;
                     buf_store4(sye, f32x4{dacc[4 * q4], dacc[4 * q4 + 1], dacc[4 * q4 + 2], dacc[4 * q4 + 3]}, eoff + 32u * q4, 0u);
                 }
             };
             read_kb(0, 0);
-#pragma unroll
-            for (int m = 0; m < 72; ++m) {
-                const int kb = m / 18, tg = (m % 18) / 6, j = m % 6, set = kb & 1;
-                const int pa = (j == 0 || j == 4) ? 1 : (j == 2 ? 2 : 0), pb = (j == 0 || j == 3) ? 1 : (j == 1 ? 2 : 0);
-                FENCE;
-                if (tg == 0)
-                    wacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[set][pa], __builtin_bit_cast(bf16x8, f[set][pb]), wacc[1], 0, 0, 0);
-                else if (tg == 1)
-                    wacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[set][pa], Bl[pb], wacc[0], 0, 0, 0);
-                else
-                    wacc[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[set][pa], Br[pb], wacc[2], 0, 0, 0);
-                FENCE;
-                // ---- the slice behind MFMA m: 18 per k-block
-                const int mm = m % 18;
-                if (mm < 3) shl(set, mm);
-                else if (mm < 6) shr(set, mm - 3);
+            // the slice behind old-style MFMA index m (18 per k-block): shifts of the X fragments first, then 12 free slices per k-block
+            // = 48: image D of the next tile in every second one of the first 24, the epilogue quads in the last 24
+            auto sliceB = [&](int m) __attribute__((always_inline)) {
+                const int kb = m / 18, mm = m % 18, set = kb & 1;
+                if (mm < 3) { if (mm < NP) shl(set, mm); }
+                else if (mm < 6) { if (mm - 3 < NP) shr(set, mm - 3); }
                 else {
-                    // 48 free slices: image D of the next tile in every second one of the first 24, the epilogue quads in the last 24
                     const int v = kb * 12 + (mm - 6);             // 0..47
                     if (v < 2 * NSB) {
                         if ((v & 1) == 0) sideB(v >> 1); else refillB(v);
-                        if (FOLD && (v == 3 || v == 9 || v == 15 || v == 21)) pyq[(v - 3) / 6] = buf_load4(spy, eoff + 32u * ((v - 3) / 6), 0u);
                     }
                     else if (v >= 24 && ((v - 24) % 3) == 0) epi2((v - 24) / 3);
                 }
-                if (mm == 12 && kb + 1 < 4) read_kb(kb + 1, set ^ 1);
+                // the next k-block's fragments (the other register set is free since this k-block began); with two slices per MFMA the
+                // old place (slice 12 of 18) left them only three MFMAs to arrive
+                if (mm == (H ? 4 : 12) && kb + 1 < 4) read_kb(kb + 1, set ^ 1);
+            };
+#pragma unroll
+            for (int m = 0; m < 12 * NPR; ++m) {
+                const int kb = m / (3 * NPR), tg = (m % (3 * NPR)) / NPR, j = m % NPR, set = kb & 1;
                 FENCE;
+                if (tg == 0)
+                    wacc[1] = mma(A[set][PA(j)], __builtin_bit_cast(u32x4, f[set][PB(j)]), wacc[1]);
+                else if (tg == 1)
+                    wacc[0] = mma(A[set][PA(j)], Bl[PB(j)], wacc[0]);
+                else
+                    wacc[2] = mma(A[set][PA(j)], Br[PB(j)], wacc[2]);
+                FENCE;
+#pragma unroll
+                for (int i_ = 0; i_ < SPM; ++i_) sliceB(m * SPM + i_);
+                FENCE;
+#ifdef WM_STAMP
+                if (m == 6 * NPR - 1) { STAMP(tsh); tm[5] += tsh - ts2; }     // end of the second k-block: first half of phase B
+#endif
             }
             okh_cur = okh_n; hsh_cur = hsh_n;
-            if (EAHEAD) {
 #pragma unroll
-                for (int q4 = 0; q4 < 4; ++q4) e1q[q4] = e1n[q4];
-            }
+            for (int q4 = 0; q4 < 4; ++q4) { e1q[q4] = e1n[q4]; if (FOLD) pyq[q4] = pyn[q4]; }
+            emk = emkn; pmk = pmkn;
         }
         STAMP(ts3);
         lds_barrier();          // image D of the next tile is complete; images G', X' of this tile are free
@@ -3500,10 +3617,10 @@ __global__ __launch_bounds__(256) void dwgrad64bf_kernel(DWArgs a) {
 #pragma unroll
     for (int k = 0; k < KW; ++k)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) out[(k * 64 + mt * 32 + mfma_row(r, half)) * 64 + nh * 32 + l31] = wacc[k][r];
+        for (int r = 0; r < 16; ++r) out[(k * 64 + mt * 32 + mfma_row(r, half)) * 64 + nh * 32 + l31] = wacc[k][r] * ginv;   // x is unscaled
 #pragma unroll
     for (int j = 0; j < 2; ++j) {       // the eight lanes of a channel pair sit 8 apart
-        float v = bsum[j];
+        float v = bsum[j] * ginv;
         v += __shfl_xor(v, 8); v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
         if (lane < 8) out[KW * 4096 + c0 + j] = v;
     }
@@ -3517,14 +3634,23 @@ __global__ __launch_bounds__(256) void dwgrad64bf_kernel(DWArgs a) {
         }
         __syncthreads();
         if (tid < 128) a.stats[(size_t)blockIdx.x * 128 + tid] = red[tid] + red[128 + tid];
+        if (H && a.dzmax) {                                   // max |y| of this workgroup's output: the next launch's gradient scale
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
+            __syncthreads();
+            if (lane == 0) red[wave] = vmax;
+            __syncthreads();
+            if (tid == 0) a.dzmax[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        }
     }
 }
 
-template <int EPI, int XPRO, bool GM>
+template <int EPI, int XPRO, bool GM, bool H>
 int launch_dwgrad64bf(const DWArgs& a, int* grid_out, hipStream_t stream) {
-    constexpr size_t lds = (size_t)(3 * 66 * 72 + 2 * 3 * 64 * 72 + 2 * 3 * 64 * 88) * 2 + 8 * 64 * sizeof(float);
+    constexpr int NP = H ? 2 : 3;
+    constexpr size_t lds = (size_t)(NP * 66 * 72 + 2 * NP * 64 * 72 + 2 * NP * 64 * 88) * 2 + 8 * 64 * sizeof(float);
     static wm::DevOnce attr_done;
-    auto kern = dwgrad64bf_kernel<EPI, XPRO, GM>;
+    auto kern = dwgrad64bf_kernel<EPI, XPRO, GM, H>;
     if (!wm::dev_done(attr_done)) {
         WM_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         wm::dev_mark(attr_done);
@@ -3533,6 +3659,7 @@ int launch_dwgrad64bf(const DWArgs& a, int* grid_out, hipStream_t stream) {
     const int grid = ntiles < kNumCU ? ntiles : kNumCU;
     *grid_out = grid;
     if (a.stats && grid < kNumCU) WM_TRY(hipMemsetAsync(a.stats, 0, sizeof(float) * 128 * kNumCU, stream));
+    if (H && a.dzmax && grid < kNumCU) WM_TRY(hipMemsetAsync(a.dzmax, 0, sizeof(float) * kNumCU, stream));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, a);
     WM_CHECK_LAUNCH();
     return 0;
@@ -3706,21 +3833,32 @@ int wm_wgrad64_bf(const float* g, const float* g2, const float* ga, const float*
 }
 
 // data gradient + weight gradient of a k3 convolution in one launch (dwgrad64bf_kernel); T % 64 == 0
+// f16 two-piece weight image for wm_dwgrad64_bf arith 1: 2 * 3 * 4096 f16 + 2 floats (mode 0 forward | 1 data gradient, as wm_pack_w64_bf)
+int wm_pack_w64_h(const float* w, void* wph, int mode, hipStream_t stream) {
+    if (!w || !wph || mode < 0 || mode > 1) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(pack_w64_h_kernel, dim3(1), dim3(1024), 0, stream, w, reinterpret_cast<unsigned short*>(wph), mode);
+    WM_CHECK_LAUNCH();
+    return 0;
+}
+
 int wm_dwgrad64_bf(const float* g, const float* g2, const float* ga, const float* gb, const float* gc, const void* wpb,
                    const float* x, const float* xa, const float* xb, const float* e1, const float* ea, const float* eb,
                    float* y, float* stats, float* partial, float* dw, float* dbias, int B, int T, int xpro, int epi, int accumulate,
-                   const void* gmask, hipStream_t stream) {
+                   const void* gmask, int arith, const float* gscale, float* dzmax, hipStream_t stream) {
     if (B <= 0 || T <= 0 || (T & 63)) return (int)hipErrorInvalidValue;
     if (!g || !g2 || !ga || !gb || !gc || !wpb || !x || !e1 || !y || !partial || !dw) return (int)hipErrorInvalidValue;
+    if (arith != 0 && (arith != 1 || !gscale)) return (int)hipErrorInvalidValue;
     DWArgs a{g, g2, ga, gb, gc, wpb, x, xa, xb, e1, ea, eb, y, stats, partial, B, T, reinterpret_cast<const unsigned*>(gmask),
-             epi == EPI_ADDSTATS ? reinterpret_cast<const unsigned*>(eb) : nullptr, epi == EPI_ADDSTATS ? ea : nullptr};
+             epi == EPI_ADDSTATS ? reinterpret_cast<const unsigned*>(eb) : nullptr, epi == EPI_ADDSTATS ? ea : nullptr, gscale, dzmax};
     int grid = 0, rc = (int)hipErrorInvalidValue;
+#define WM_DW(E, X, G) (arith ? launch_dwgrad64bf<E, X, G, true>(a, &grid, stream) : launch_dwgrad64bf<E, X, G, false>(a, &grid, stream))
     if (epi == EPI_RELUMASK && xpro == PRO_BNRELU && stats && xa && xb && ea && eb)
-        rc = gmask ? launch_dwgrad64bf<EPI_RELUMASK, PRO_BNRELU, true>(a, &grid, stream) : launch_dwgrad64bf<EPI_RELUMASK, PRO_BNRELU, false>(a, &grid, stream);
+        rc = gmask ? WM_DW(EPI_RELUMASK, PRO_BNRELU, true) : WM_DW(EPI_RELUMASK, PRO_BNRELU, false);
     else if (epi == EPI_ADD && xpro == PRO_NONE && !stats)
-        rc = gmask ? launch_dwgrad64bf<EPI_ADD, PRO_NONE, true>(a, &grid, stream) : launch_dwgrad64bf<EPI_ADD, PRO_NONE, false>(a, &grid, stream);
+        rc = gmask ? WM_DW(EPI_ADD, PRO_NONE, true) : WM_DW(EPI_ADD, PRO_NONE, false);
     else if (epi == EPI_ADDSTATS && xpro == PRO_NONE && stats && ea && eb && gmask)
-        rc = launch_dwgrad64bf<EPI_ADDSTATS, PRO_NONE, true>(a, &grid, stream);
+        rc = WM_DW(EPI_ADDSTATS, PRO_NONE, true);
+#undef WM_DW
     if (rc) return rc;
     const int n = 3 * 4096 + 64;
     hipLaunchKernelGGL(wgrad64_reduce_kernel, dim3((n + 63) / 64), dim3(256), 0, stream, (const float*)partial, grid, 3, 0, dw,

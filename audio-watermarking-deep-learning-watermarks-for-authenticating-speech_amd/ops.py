@@ -149,7 +149,8 @@ _CONV = {"bf16x6": _os.environ.get("WM_CONV_BF16X6", "1") == "1", "schedule": 2,
          "one_launch_eval": _os.environ.get("WM_RESBLOCK_ONE_LAUNCH", "1") == "1",
          "fused_bwd": _os.environ.get("WM_FUSED_BWD", "1") == "1",
          "mask_on_load": _os.environ.get("WM_MASK_ON_LOAD", "1") == "1",
-         "pair_fold": _os.environ.get("WM_PAIR_FOLD", "1") == "1"}
+         "pair_fold": _os.environ.get("WM_PAIR_FOLD", "1") == "1",
+         "bwd_f16x3": _os.environ.get("WM_BWD_F16X3", "1") == "1"}
 
 
 def set_conv_bf_schedule(schedule: int):
@@ -176,6 +177,19 @@ def set_mask_on_load(on: bool):
     """fused ResBlock backward: 1 (default) the masked gradient dz2 = g * (out > 0) is never written -- the reduction pass forms
     only the BatchNorm sums and wm_dwgrad64_bf masks g on load; 0 it is materialised first.  WM_MASK_ON_LOAD=0/1 sets the default."""
     _CONV["mask_on_load"] = bool(on)
+
+
+def set_bwd_f16x3(on: bool):
+    """fused ResBlock backward arithmetic: 1 (default) f16 two-piece split, three products per product on the f16 matrix cores
+    (half the matrix work of bf16x6; power-of-two scales from max |w| and max |A| max |dz| keep the operands in the f16 range),
+    0 bf16x6 as in the forward.  WM_BWD_F16X3=0/1 sets the default."""
+    _CONV["bwd_f16x3"] = bool(on)
+
+
+def pack_w64_h(w: torch.Tensor, mode: int) -> torch.Tensor:
+    wph = torch.empty(2 * 3 * 4096 + 4, dtype=torch.int16, device=w.device)      # two f16 pieces + {ws, 1 / ws}
+    lib.wm_pack_w64_h(_p(w), _p(wph), mode, _stream())
+    return wph
 
 
 def set_pair_fold(on: bool):
@@ -296,10 +310,10 @@ class ResBlockFn(GradAwareFunction):
             return (dx,) + grads + (None,) * 7
         part = _f32(max(B, 1) * 128, device=dev)
         dz2 = torch.empty_like(x)
-        lib.wm_relu_bwd_reduce_mask(_p(g_out), _p(mask), _p(y2), _p(dz2), _p(part), B, T, st)
+        lib.wm_relu_bwd_reduce_mask(_p(g_out), _p(mask), _p(y2), _p(dz2), _p(part), None, B, T, st)
         k2 = _f32(4, 64, device=dev)          # A, B (hi), B (lo), C  -- B is handed over as hi + lo words
         dg2, dbe2 = _f32(64, device=dev), _f32(64, device=dev)
-        lib.wm_bn_bwd_finalize(_p(part), B, n, _p(g2), _p(mu2), _p(is2), _p(k2[0]), _p(k2[1]), _p(k2[3]), _p(dg2), _p(dbe2), 0, ev, st)
+        lib.wm_bn_bwd_finalize(_p(part), B, n, _p(g2), _p(mu2), _p(is2), _p(k2[0]), _p(k2[1]), _p(k2[3]), _p(dg2), _p(dbe2), 0, ev, None, 0, None, st)
         # conv2: data gradient (+ ReLU mask + BN1-backward reductions in the epilogue) and weight gradient
         dz1 = torch.empty_like(x)
         stats = _f32(NCU * 128, device=dev)
@@ -320,7 +334,7 @@ class ResBlockFn(GradAwareFunction):
             wgrad2()
         k1 = _f32(4, 64, device=dev)
         dg1, dbe1 = _f32(64, device=dev), _f32(64, device=dev)
-        lib.wm_bn_bwd_finalize(_p(stats), NCU, n, _p(g1), _p(mu1), _p(is1), _p(k1[0]), _p(k1[1]), _p(k1[3]), _p(dg1), _p(dbe1), 0, ev, st)
+        lib.wm_bn_bwd_finalize(_p(stats), NCU, n, _p(g1), _p(mu1), _p(is1), _p(k1[0]), _p(k1[1]), _p(k1[3]), _p(dg1), _p(dbe1), 0, ev, None, 0, None, st)
         # conv1: data gradient + residual path, weight gradient
         dx = torch.empty_like(x)
         _conv3(dz1, y1, w1, 1, k1[0], k1[1], k1[3], None, dz2, None, None, dx, None, B, T, 3, 2)
@@ -342,51 +356,64 @@ class ResBlockFn(GradAwareFunction):
 
 def _resblock_bwd_fused(saved, training, g_out, pre=None, fold=None):
     """Backward of one ResBlock on the fused path (data + weight gradient of each convolution in one launch, T % 64 == 0).
-    g_out: gradient w.r.t. the block output.  `pre` = stats partials [NCU,2,64] when g_out ALREADY is dz2 = g (out > 0) and its two
-    BatchNorm sums exist (made by the next block's folded conv1 launch): no reduction pass, no mask.  `fold` = (mask, y2) of the
-    block BEFORE this one: the conv1 launch then writes that block's dz2 instead of the plain input gradient and returns its
-    BatchNorm-sum partials as the third value.  Returns (dx, (dw1, db1, dg1, dbe1, dw2, db2, dg2, dbe2), fold partials | None)."""
+    g_out: gradient w.r.t. the block output.  `pre` = (stats partials [NCU,2,64], max |dz| per workgroup [NCU]) when g_out ALREADY is
+    dz2 = g (out > 0) and its two BatchNorm sums exist (made by the next block's folded conv1 launch): no reduction pass, no mask.
+    `fold` = (mask, y2) of the block BEFORE this one: the conv1 launch then writes that block's dz2 instead of the plain input
+    gradient and returns (its BatchNorm-sum partials, its max |dz| per workgroup) as the third value.
+    Returns (dx, (dw1, db1, dg1, dbe1, dw2, db2, dg2, dbe2), fold outputs | None)."""
     x, y1, y2, mask, cst, w1, w2, g1, g2 = saved
     sc1, sh1, mu1, is1, sc2, sh2, mu2, is2 = cst.unbind(0)
     B, _, T = x.shape
     dev, st = x.device, _stream()
     ev = 0 if training else 1
     n = float(B * T)
+    h = 1 if _CONV["bwd_f16x3"] else 0        # arithmetic of the two launches; the f16 split needs the gradient's scale (max |dz|)
+    pack = pack_w64_h if h else pack_w64_bf
     k2 = _f32(4, 64, device=dev)          # A, B (hi), B (lo), C  -- B is handed over as hi + lo words
     dg2, dbe2 = _f32(64, device=dev), _f32(64, device=dev)
+    gs2 = _f32(2, device=dev) if h else None
     if pre is not None:
+        ppart, pmax = pre
         gsrc, gm = g_out, None
-        lib.wm_bn_bwd_finalize(_p(pre), NCU, n, _p(g2), _p(mu2), _p(is2), _p(k2[0]), _p(k2[1]), _p(k2[3]), _p(dg2), _p(dbe2), 0, ev, st)
+        lib.wm_bn_bwd_finalize(_p(ppart), NCU, n, _p(g2), _p(mu2), _p(is2), _p(k2[0]), _p(k2[1]), _p(k2[3]), _p(dg2), _p(dbe2), 0, ev,
+                               _p(pmax) if h else None, NCU, _p(gs2), st)
     else:
         # dz2 = g_out * (out > 0) is never written (default): the reduction pass only forms the two BatchNorm sums, and the two
         # convolution-backward launches mask g_out with the same bits while they load it (wm_dwgrad64_bf's gmask)
         part = _f32(max(B, 1) * 128, device=dev)
+        dzm = _f32(B * 64, device=dev) if h else None
         dz2 = None if _CONV["mask_on_load"] else torch.empty_like(x)
-        lib.wm_relu_bwd_reduce_mask(_p(g_out), _p(mask), _p(y2), _p(dz2), _p(part), B, T, st)
-        lib.wm_bn_bwd_finalize(_p(part), B, n, _p(g2), _p(mu2), _p(is2), _p(k2[0]), _p(k2[1]), _p(k2[3]), _p(dg2), _p(dbe2), 0, ev, st)
+        lib.wm_relu_bwd_reduce_mask(_p(g_out), _p(mask), _p(y2), _p(dz2), _p(part), _p(dzm), B, T, st)
+        lib.wm_bn_bwd_finalize(_p(part), B, n, _p(g2), _p(mu2), _p(is2), _p(k2[0]), _p(k2[1]), _p(k2[3]), _p(dg2), _p(dbe2), 0, ev,
+                               _p(dzm), B * 64, _p(gs2), st)
         gsrc, gm = (g_out, mask) if dz2 is None else (dz2, None)
     # conv2: data gradient (+ ReLU mask + BN1-backward reductions in the epilogue) and weight gradient
     dz1 = torch.empty_like(x)
     stats = _f32(NCU * 128, device=dev)
+    dzm1 = _f32(NCU, device=dev) if h else None          # max |dz1| per workgroup, written by the conv2-pair launch
     dw2, db2, dw1, db1 = torch.empty_like(w2), _f32(64, device=dev), torch.empty_like(w1), _f32(64, device=dev)
     wpart = _f32(NCU * (3 * 4096 + 64), device=dev)
-    lib.wm_dwgrad64_bf(_p(gsrc), _p(y2), _p(k2[0]), _p(k2[1]), _p(k2[3]), _p(pack_w64_bf(w2, 1)), _p(y1), _p(sc1), _p(sh1),
-                       _p(y1), _p(sc1), _p(sh1), _p(dz1), _p(stats), _p(wpart), _p(dw2), _p(db2), B, T, 1, 1, 0, _p(gm), st)
+    lib.wm_dwgrad64_bf(_p(gsrc), _p(y2), _p(k2[0]), _p(k2[1]), _p(k2[3]), _p(pack(w2, 1)), _p(y1), _p(sc1), _p(sh1),
+                       _p(y1), _p(sc1), _p(sh1), _p(dz1), _p(stats), _p(wpart), _p(dw2), _p(db2), B, T, 1, 1, 0, _p(gm), h, _p(gs2), _p(dzm1), st)
     k1 = _f32(4, 64, device=dev)
     dg1, dbe1 = _f32(64, device=dev), _f32(64, device=dev)
-    lib.wm_bn_bwd_finalize(_p(stats), NCU, n, _p(g1), _p(mu1), _p(is1), _p(k1[0]), _p(k1[1]), _p(k1[3]), _p(dg1), _p(dbe1), 0, ev, st)
+    gs1 = _f32(2, device=dev) if h else None
+    lib.wm_bn_bwd_finalize(_p(stats), NCU, n, _p(g1), _p(mu1), _p(is1), _p(k1[0]), _p(k1[1]), _p(k1[3]), _p(dg1), _p(dbe1), 0, ev,
+                           _p(dzm1), NCU, _p(gs1), st)
     dx = torch.empty_like(x)
-    fpart = None
+    fout = None
     if fold is not None and gm is not None:
         # conv1 pair that also does the PREVIOUS block's ReLU backward and BatchNorm sums (epi 8): dx leaves as that block's dz2
         pmask, py2 = fold
         fpart = _f32(NCU * 128, device=dev)
-        lib.wm_dwgrad64_bf(_p(dz1), _p(y1), _p(k1[0]), _p(k1[1]), _p(k1[3]), _p(pack_w64_bf(w1, 1)), _p(x), None, None,
-                           _p(gsrc), _p(py2), _p(pmask), _p(dx), _p(fpart), _p(wpart), _p(dw1), _p(db1), B, T, 0, 8, 0, _p(gm), st)
+        fmax = _f32(NCU, device=dev) if h else None
+        lib.wm_dwgrad64_bf(_p(dz1), _p(y1), _p(k1[0]), _p(k1[1]), _p(k1[3]), _p(pack(w1, 1)), _p(x), None, None,
+                           _p(gsrc), _p(py2), _p(pmask), _p(dx), _p(fpart), _p(wpart), _p(dw1), _p(db1), B, T, 0, 8, 0, _p(gm), h, _p(gs1), _p(fmax), st)
+        fout = (fpart, fmax)
     else:
-        lib.wm_dwgrad64_bf(_p(dz1), _p(y1), _p(k1[0]), _p(k1[1]), _p(k1[3]), _p(pack_w64_bf(w1, 1)), _p(x), None, None,
-                           _p(gsrc), None, None, _p(dx), None, _p(wpart), _p(dw1), _p(db1), B, T, 0, 2, 0, _p(gm), st)
-    return dx, (dw1, db1, dg1, dbe1, dw2, db2, dg2, dbe2), fpart
+        lib.wm_dwgrad64_bf(_p(dz1), _p(y1), _p(k1[0]), _p(k1[1]), _p(k1[3]), _p(pack(w1, 1)), _p(x), None, None,
+                           _p(gsrc), None, None, _p(dx), None, _p(wpart), _p(dw1), _p(db1), B, T, 0, 2, 0, _p(gm), h, _p(gs1), None, st)
+    return dx, (dw1, db1, dg1, dbe1, dw2, db2, dg2, dbe2), fout
 
 
 class ResBlockPairFn(GradAwareFunction):
@@ -412,8 +439,8 @@ class ResBlockPairFn(GradAwareFunction):
         sv = ctx.saved_tensors
         s1_, s2_ = sv[:9], sv[9:]
         g_out = g_out.contiguous()
-        dmid, grads2, fpart = _resblock_bwd_fused(s2_, ctx.training, g_out, fold=(s1_[3], s1_[2]))
-        dx, grads1, _ = _resblock_bwd_fused(s1_, ctx.training, dmid, pre=fpart)
+        dmid, grads2, fout = _resblock_bwd_fused(s2_, ctx.training, g_out, fold=(s1_[3], s1_[2]))
+        dx, grads1, _ = _resblock_bwd_fused(s1_, ctx.training, dmid, pre=fout)
         return (dx,) + grads1 + (None,) * 6 + grads2 + (None,) * 6 + (None,)
 
 

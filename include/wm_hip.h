@@ -92,7 +92,13 @@ int wm_resblock_eval_bf(const float* x, const void* w1pb, const void* w2pb, cons
 int wm_dwgrad64_bf(const float* g, const float* g2, const float* ga, const float* gb, const float* gc, const void* wpb,
                    const float* x, const float* xa, const float* xb, const float* e1, const float* ea, const float* eb,
                    float* y, float* stats, float* partial, float* dw, float* dbias, int B, int T, int xpro, int epi, int accumulate,
-                   const void* gmask, wm_stream_t stream);
+                   const void* gmask, int arith, const float* gscale, float* dzmax, wm_stream_t stream);
+/* arith 0: bf16 three-piece split, six piece products (bf16x6); wpb from wm_pack_w64_bf.
+ * arith 1: f16 TWO-piece split (22 bits per operand), three products on v_mfma_f32_32x32x16_f16 -- half the matrix work of arith 0,
+ *          used for the BACKWARD only (gradient tolerance; the forward stays bf16x6).  wpb from wm_pack_w64_h (weights scaled by a
+ *          power of two chosen from max |w|, stored behind the image); gscale = wm_bn_bwd_finalize's {gs, 1 / gs} for THIS launch's
+ *          g; dzmax (optional, epi 1 / 8): 256 floats, max |y| per workgroup = the dzmax input of the next launch's finalize. */
+int wm_pack_w64_h(const float* w, void* wph, int mode, wm_stream_t stream);      /* 2 * 3 * 4096 f16 + 2 floats */
 
 /* bf16x6 build of the 7-tap ConvTranspose1d(64,64,7,padding=3) (py/main16.py:144): wpb [3][7][64][64] uint16 from
  * wm_pack_w64_bf7 (mode 2 forward | 3 data gradient).  pro 0 x | 2 x + vec[b*64+c]; epi 0 + bias[c] | 3 none. */
@@ -135,12 +141,14 @@ int wm_relu_bwd_reduce(const float* g, const float* out, const float* y2, float*
  * ResBlock training uses. */
 int wm_bn_add_relu_mask(const float* x, const float* y2, const float* scale, const float* shift, float* out, void* mask, int B, int T,
                         wm_stream_t stream);
-int wm_relu_bwd_reduce_mask(const float* g, const void* mask, const float* y2, float* dz, float* partial, int B, int T,
-                            wm_stream_t stream);
+int wm_relu_bwd_reduce_mask(const float* g, const void* mask, const float* y2, float* dz, float* partial, float* dzmax, int B, int T,
+                            wm_stream_t stream);      /* dzmax (optional): B * 64 floats, max |dz| per row (wm_bn_bwd_finalize's gscale) */
 /* A, Cc: [64]; Bc: [2][64] (hi, lo words of the offset, see wm_conv64 pro 3) */
 int wm_bn_bwd_finalize(const float* partials, int nparts, double count, const float* gamma, const float* save_mean,
                        const float* save_invstd, float* A, float* Bc, float* Cc, float* dgamma, float* dbeta,
-                       int accumulate, int eval_mode, wm_stream_t stream);
+                       int accumulate, int eval_mode, const float* dzmax, int nmax, float* gscale, wm_stream_t stream);
+/* gscale (optional, 2 floats; needs dzmax [nmax] = max |dz| per producer block): {gs, 1 / gs}, gs = the power of two that brings
+ * max |A| * max |dz| to 2^9 -- the scale under which wm_dwgrad64_bf (arith 1) splits the rebuilt gradient into two f16 pieces. */
 
 /* ---- stem / heads: Conv1d(1,64,7,p=3) :134,:177 ; Conv1d(64,1,1) :146 ; Conv1d(64,1+bits,1) :180 (+permute :186) */
 int wm_stem_fwd(const float* s, const float* w, const float* bias, float* y, int B, int T, wm_stream_t stream);

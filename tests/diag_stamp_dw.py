@@ -18,14 +18,16 @@ dw = torch.empty(64, 64, 3, device=dev); db = torch.empty(64, device=dev)
 buf = torch.zeros(256 * 4 * 6, dtype=torch.int64, device=dev)
 vp = ctypes.c_void_p
 L.wm_debug_set_stamp_buffer(vp(buf.data_ptr()))
-wpb = torch.empty(3 * 3 * 4096, dtype=torch.int16, device=dev)
-L.wm_pack_w64_bf(vp(w.data_ptr()), vp(wpb.data_ptr()), 1, None)
+ARITH = 1 if os.environ.get("WM_DIAG_ARITH", "1") == "1" else 0       # 1: f16 two-piece split (default backward), 0: bf16x6
+wpb = torch.empty(3 * 3 * 4096 + 4, dtype=torch.int16, device=dev)
+gsc = torch.tensor([1.0, 1.0], device=dev)
+(L.wm_pack_w64_h if ARITH else L.wm_pack_w64_bf)(vp(w.data_ptr()), vp(wpb.data_ptr()), 1, None)
 def run(name, xpro, epi):
     args = [vp(dz.data_ptr()), vp(y2.data_ptr()), vp(k[0].data_ptr()), vp(k[1].data_ptr()), vp(k[3].data_ptr()), vp(wpb.data_ptr()),
             vp(y1.data_ptr()), vp(sc.data_ptr()) if xpro else None, vp(sh.data_ptr()) if xpro else None,
             vp(y1.data_ptr()), vp(sc.data_ptr()) if epi == 1 else None, vp(sh.data_ptr()) if epi == 1 else None,
             vp(out.data_ptr()), vp(stats.data_ptr()) if epi == 1 else None, vp(wpart.data_ptr()), vp(dw.data_ptr()), vp(db.data_ptr()),
-            B, T, xpro, epi, 0, None, None]
+            B, T, xpro, epi, 0, None, ARITH, vp(gsc.data_ptr()) if ARITH else None, None, None]
     e0, e1 = torch.cuda.Event(True), torch.cuda.Event(True)
     for _ in range(3):
         buf.zero_(); torch.cuda.synchronize(); e0.record(); rc = L.wm_dwgrad64_bf(*args); e1.record(); torch.cuda.synchronize()
@@ -33,7 +35,7 @@ def run(name, xpro, epi):
     ms = e0.elapsed_time(e1)
     ntile = B * (T // 64) / 256
     d = buf.view(256, 4, 6).double().mean(dim=(0, 1)) / ntile
-    names = ["phase A (dgrad)", "barrier 1", "phase B (wgrad)", "barrier 2", "(of barrier 1: LDS drain)"]
+    names = ["phase A (dgrad)", "barrier 1", "phase B (wgrad)", "barrier 2", "(of barrier 1: LDS drain)", "(of phase B: first two k-blocks)"]
     print(f"{name}: B={B} {ms:.3f} ms, per 64-step tile: " + "  ".join(f"{n} {v:6.0f}" for n, v in zip(names, d)) +
           f"  total {float(d[:4].sum()):6.0f} ticks = {ms*1e3/ntile:.2f} us")
     pw = buf.view(256, 4, 6).double().mean(dim=0) / ntile          # per wave

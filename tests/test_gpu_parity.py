@@ -348,10 +348,12 @@ def test_relu_mask_kernels_bit_exact(awm, dev, B, T):
     dz_a, dz_b = torch.empty_like(x), torch.empty_like(x)
     part_a, part_b, part_c = (torch.zeros(B * 128, device=dev) for _ in range(3))
     lib.wm_relu_bwd_reduce(p(g), p(out_a), p(y2), p(dz_a), p(part_a), B, T, st)
-    lib.wm_relu_bwd_reduce_mask(p(g), p(mask), p(y2), p(dz_b), p(part_b), B, T, st)
-    lib.wm_relu_bwd_reduce_mask(p(g), p(mask), p(y2), None, p(part_c), B, T, st)          # the sums alone (dz never written)
+    dzmax = torch.full((B * 64,), -1.0, device=dev)
+    lib.wm_relu_bwd_reduce_mask(p(g), p(mask), p(y2), p(dz_b), p(part_b), None, B, T, st)
+    lib.wm_relu_bwd_reduce_mask(p(g), p(mask), p(y2), None, p(part_c), p(dzmax), B, T, st)   # the sums alone (dz never written) + max |dz| per row
     assert torch.equal(dz_a, dz_b) and torch.equal(part_a, part_b) and torch.equal(part_a, part_c)
     assert torch.equal(dz_a, torch.where(out_a > 0, g, torch.zeros_like(g)))
+    assert torch.equal(dzmax, dz_a.abs().amax(dim=2).reshape(-1))
 
 
 @pytest.mark.parametrize("B,T", [(1, 64), (2, 192), (3, 640), (2, 16000)])
@@ -387,6 +389,50 @@ def test_resblock_backward_mask_on_load_is_bit_identical(awm, dev, B, T):
         awm.ops.set_mask_on_load(True)
     for k in res[True]:
         assert torch.equal(res[True][k], res[False][k]), (k, float((res[True][k] - res[False][k]).abs().max()))
+
+
+@pytest.mark.parametrize("gscale", [1.0, 1e-9, 3e4])
+@pytest.mark.parametrize("B,T", [(2, 192), (2, 4096)])
+def test_resblock_backward_f16_split_is_fp32_grade(awm, dev, B, T, gscale):
+    """The fused ResBlock backward in its default arithmetic -- f16 two-piece split, three products per product on the f16 matrix
+    cores, operands brought into the f16 range by power-of-two scales (weights: max |w|; gradient: max |A| max |dz| from the
+    reduction pass / the previous launch) -- against the same launches in bf16x6, with upstream gradients of ordinary size, at the
+    1e-9 scale of a mean-reduced loss and at 3e4: every gradient within 2e-6 of its maximum element-wise (two operands at 2^-22
+    each; bf16x6 itself sits 2.7e-7 from an fp64 convolution), and no overflow / underflow at either extreme."""
+    if not awm.ops.conv_bf16x6():
+        pytest.skip("fused backward is the bf16x6 / f16 build")
+    sd = _resblock_state(55)
+    x = rnd(B, 64, T, seed=47).abs() * 0.7
+    g = rnd(B, 64, T, seed=48) * gscale
+    res, ar = {}, []
+    orig = awm.lib.wm_dwgrad64_bf
+
+    def spy(*a):
+        ar.append(a[23])                                       # arith
+        return orig(*a)
+    awm.lib.wm_dwgrad64_bf = spy
+    try:
+        for on in (True, False):
+            awm.ops.set_bwd_f16x3(on)
+            del ar[:]
+            m = awm.ResBlock(64)
+            m.load_state_dict(sd)
+            m.to(dev).train()
+            xd = x.to(dev).requires_grad_()
+            m(xd).backward(g.to(dev))
+            assert ar == [int(on)] * 2, ar
+            res[on] = {"dx": xd.grad.clone(), **{k: p.grad.clone() for k, p in m.named_parameters()}}
+    finally:
+        awm.lib.wm_dwgrad64_bf = orig
+        awm.ops.set_bwd_f16x3(True)
+    wmax = float(res[False]["block.0.weight"].abs().max())
+    for k in res[True]:
+        a, b = res[True][k], res[False][k]
+        assert torch.isfinite(a).all(), k
+        if k.endswith("block.0.bias") or k.endswith("block.3.bias"):
+            assert float(a.abs().max()) <= 1e-3 * wmax + 1e-4 * gscale and float(b.abs().max()) <= 1e-3 * wmax + 1e-4 * gscale
+            continue
+        check_elementwise(a, b.cpu(), f"f16 split vs bf16x6 {k} (gradient scale {gscale})", rtol=1e-5, atol_of_max=2e-6)
 
 
 @pytest.mark.parametrize("B,T", [(2, 128), (3, 704)])
