@@ -3017,6 +3017,13 @@ __global__ __launch_bounds__(256) void dwgrad64bf_kernel(DWArgs a) {
     unsigned short* Gb0 = Db + DIMG;                                           // [2][NP][64][PG]
     unsigned short* Xb0 = Gb0 + 2 * GIMG;                                      // [2][NP][64][PX]     element XO + (t - t0)
     float* Cs = reinterpret_cast<float*>(Xb0 + 2 * XIMG);                      // [8][64]
+    // H: a wave-private [32 channels][32 steps (+4)] exchange tile.  In the accumulator layout a lane owns one channel, so a dwordx4
+    // access touches 32 rows with 16 bytes each; such a store (load) holds the wave at issue for ~300 cycles (measured: the four
+    // epilogue stores were 1 200 of a tile's 7 000 cycles).  Epilogue operands and results therefore cross HBM in ROW layout (a lane
+    // = 4 steps, 8 lanes = one 128-byte row segment, 8 rows per instruction) and change layout through this tile.
+    constexpr bool XL = H;
+    constexpr int EXP = 36;
+    float* Ex = Cs + 8 * 64 + (threadIdx.x >> 6) * (32 * EXP);
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int mt = wave & 1, nh = wave >> 1;           // data gradient: 32 output rows x 32 columns; weight gradient: block (mt, nt = nh)
@@ -3365,6 +3372,12 @@ __global__ __launch_bounds__(256) void dwgrad64bf_kernel(DWArgs a) {
     f32x4 e1n[4];
     unsigned emk = 0u, pmk = 0u, emkn = 0u, pmkn = 0u;
     f32x4 pyq[FOLD ? 4 : 1], pyn[FOLD ? 4 : 1];
+    f32x4 ec[XL ? 4 : 1], pyc[(XL && FOLD) ? 4 : 1];     // row-layout staging of the next tile's epilogue operands
+    const int xrow = lane >> 3, xcol = 4 * (lane & 7);       // row layout: lane -> (row xrow + 8 r, steps xcol .. xcol + 3)
+    const unsigned xlane = (unsigned)(xrow * T + xcol) * 4u;
+    unsigned row8T[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) row8T[r] = (unsigned)(8 * r * T) * 4u;
     const float kea = (EPI == EPI_RELUMASK) ? Cs[384 + 32 * mt + l31] : 0.f, keb = (EPI == EPI_RELUMASK) ? Cs[448 + 32 * mt + l31] : 0.f;
     int buf = 0;
 #ifdef WM_STAMP
@@ -3431,6 +3444,7 @@ __global__ __launch_bounds__(256) void dwgrad64bf_kernel(DWArgs a) {
         const wm_srd_t smen = GME ? make_srd(reinterpret_cast<const float*>(a.gmask) + ((size_t)bnx * 64 + 32 * mt) * nwm,
                                              (size_t)32 * nwm * sizeof(unsigned)) : se1;
         const unsigned emoffn = ((unsigned)l31 * nwm + ((unsigned)t0nx >> 5) + (unsigned)nh) * 4u;
+        const unsigned xoffn = xlane + (unsigned)(t0nx + 32 * nh) * 4u, xoff = xlane + (unsigned)(t0 + 32 * nh) * 4u;
 
         STAMP(ts0);
         // ---------------- phase A: data gradient out of image D
@@ -3462,11 +3476,14 @@ __global__ __launch_bounds__(256) void dwgrad64bf_kernel(DWArgs a) {
 #pragma unroll
                     for (int i_ = 0; i_ < SPM; ++i_) {
                         const int m = (s * NPR + j) * SPM + i_;          // 0..71
+                        if (XL && m < 8 && (m & 1)) ec[m >> 1] = buf_load4(se1n, xoffn, row8T[m >> 1]);
+                        if (XL && FOLD && m >= 8 && m < 16 && (m & 1)) pyc[(m - 8) >> 1] = buf_load4(spyn, xoffn, row8T[(m - 8) >> 1]);
                         if (m < NSA) {
                             sideA(m, Gn, Xn); refillA(m);
                             if (GME && m == 61) emkn = __builtin_bit_cast(unsigned, buf_load(smen, emoffn, 0u));
                             if (FOLD && m == 62) pmkn = __builtin_bit_cast(unsigned, buf_load(spmn, emoffn, 0u));
                         }
+                        else if (XL) { }
                         else if (((m - NSA) & 1) == 0) e1n[(m - NSA) >> 1] = buf_load4(se1n, eoffn + 32u * ((m - NSA) >> 1), 0u);
                         else if (FOLD) pyn[(m - NSA) >> 1] = buf_load4(spyn, eoffn + 32u * ((m - NSA) >> 1), 0u);
                     }
@@ -3550,7 +3567,9 @@ __global__ __launch_bounds__(256) void dwgrad64bf_kernel(DWArgs a) {
                 if (H && STATS) vmax = fmaxf(vmax, fmaxf(fabsf(v0), fabsf(v1)));
                 if (i & 1) {
                     const int q4 = i >> 1;
-                    buf_store4(sye, f32x4{dacc[4 * q4], dacc[4 * q4 + 1], dacc[4 * q4 + 2], dacc[4 * q4 + 3]}, eoff + 32u * q4, 0u);
+                    const f32x4 quad = {dacc[4 * q4], dacc[4 * q4 + 1], dacc[4 * q4 + 2], dacc[4 * q4 + 3]};
+                    if (XL) *reinterpret_cast<f32x4*>(Ex + l31 * EXP + 8 * q4 + 4 * half) = quad;
+                    else buf_store4(sye, quad, eoff + 32u * q4, 0u);
                 }
             };
             read_kb(0, 0);
@@ -3564,6 +3583,31 @@ __global__ __launch_bounds__(256) void dwgrad64bf_kernel(DWArgs a) {
                     const int v = kb * 12 + (mm - 6);             // 0..47
                     if (v < 2 * NSB) {
                         if ((v & 1) == 0) sideB(v >> 1); else refillB(v);
+                        if (XL) {       // the next tile's epilogue operands: row layout -> exchange tile -> accumulator layout
+                            if (v == 3) {
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) *reinterpret_cast<f32x4*>(Ex + (xrow + 8 * r) * EXP + xcol) = ec[r];
+                            }
+                            if (v == 5) {
+#pragma unroll
+                                for (int q4 = 0; q4 < 4; ++q4) e1n[q4] = *reinterpret_cast<const f32x4*>(Ex + l31 * EXP + 8 * q4 + 4 * half);
+                            }
+                            if (FOLD && v == 9) {
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) *reinterpret_cast<f32x4*>(Ex + (xrow + 8 * r) * EXP + xcol) = pyc[r];
+                            }
+                            if (FOLD && v == 11) {
+#pragma unroll
+                                for (int q4 = 0; q4 < 4; ++q4) pyn[q4] = *reinterpret_cast<const f32x4*>(Ex + l31 * EXP + 8 * q4 + 4 * half);
+                            }
+                        }
+                    }
+                    else if (XL) {      // epilogue quads every second slice, then the result tile leaves in row layout
+                        if (v < 40) { if ((v & 1) == 0) epi2((v - 24) >> 1); }
+                        else if ((v & 1) == 0) {
+                            const int r = (v - 40) >> 1;
+                            buf_store4(sye, *reinterpret_cast<const f32x4*>(Ex + (xrow + 8 * r) * EXP + xcol), xoff, row8T[r]);
+                        }
                     }
                     else if (v >= 24 && ((v - 24) % 3) == 0) epi2((v - 24) / 3);
                 }
@@ -3648,7 +3692,8 @@ __global__ __launch_bounds__(256) void dwgrad64bf_kernel(DWArgs a) {
 template <int EPI, int XPRO, bool GM, bool H>
 int launch_dwgrad64bf(const DWArgs& a, int* grid_out, hipStream_t stream) {
     constexpr int NP = H ? 2 : 3;
-    constexpr size_t lds = (size_t)(NP * 66 * 72 + 2 * NP * 64 * 72 + 2 * NP * 64 * 88) * 2 + 8 * 64 * sizeof(float);
+    constexpr size_t lds = (size_t)(NP * 66 * 72 + 2 * NP * 64 * 72 + 2 * NP * 64 * 88) * 2 + 8 * 64 * sizeof(float) +
+                           (H ? (size_t)4 * 32 * 36 * sizeof(float) : 0);
     static wm::DevOnce attr_done;
     auto kern = dwgrad64bf_kernel<EPI, XPRO, GM, H>;
     if (!wm::dev_done(attr_done)) {

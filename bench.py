@@ -291,12 +291,17 @@ def kernel_timers(lib, model, mode, bf_mode, batch):
     # args: dz y A Bc C wpb xin sc sh e1 ea eb dx stats wpart dw db B T pro epi accumulate gmask stream; epi 1 = conv2 pair (reads
     # dz2 y2 y1, writes dz1: 4 frames), epi 2 = conv1 pair (reads dz1 y1 x dz2, writes dx: 5 frames), epi 8 = conv1 pair that also
     # does the previous block's ReLU backward + BatchNorm sums (one more frame read: 6)
+    h = _ops._CONV["bwd_f16x3"]     # backward arithmetic: f16 two-piece split (three products per product) | bf16x6 (six)
     dw = dict(timer=LaunchTimer(lib, "wm_dwgrad64_bf", lambda a: True,
                                 lambda a: (2.0 * 2.0 * 64 * 64 * 3 * a[18] * a[17], {1: 4.0, 2: 5.0, 8: 6.0}[a[20]] * 64 * a[18] * 4 * a[17])),
-              kernel="dwgrad64bf_kernel<1,1,*> + <2,0,*> + <8,0,true> (wm_dwgrad64_bf: data gradient AND weight gradient of a ResBlock "
+              kernel="dwgrad64bf_kernel<1,1,..> + <2,0,..> + <8,0,..> (wm_dwgrad64_bf: data gradient AND weight gradient of a ResBlock "
                      "Conv1d(64,64,3) in one launch -- BN-backward rebuilt and the ReLU mask applied on load, ReLU mask / BN sums / residual add "
-                     "in the epilogue; bf16x6 split products, fp32 accumulate; 31 % of the step's kernel time)",
-              peak=BF16X6_PEAK, note=BF16X6_NOTE, pmc=pmc16, pmc_prefixes=("dwgrad64bf_kernel<",))
+                     "in the epilogue; " + ("f16 two-piece split, three piece products per product on v_mfma_f32_32x32x16_f16" if h else
+                                            "bf16x6 split products") + ", fp32 accumulate; the largest share of the step's kernel time)",
+              peak=(PEAK_BF16_MFMA_TFLOPS / 3.0) if h else BF16X6_PEAK,
+              note=("f16 dense MFMA peak 2500 TFLOP/s / 3 f16 piece products per product (the bf16x6 build of rounds 1-2 was priced "
+                    "against 2500 / 6 = 416.7)") if h else BF16X6_NOTE,
+              pmc=pmc16, pmc_prefixes=("dwgrad64bf_kernel<",))
     return [dw, fwd]
 
 
@@ -309,7 +314,8 @@ def roofline_of(entry):
     traffic, tnote = pmc_traffic(entry["pmc"], entry["pmc_prefixes"]) if entry["pmc"] else (None, "no PMC pass exists for this batch size")
     return {"bound": "mfma", "achieved": round(ach, 2), "peak": round(entry["peak"], 1), "unit": "TFLOP/s",
             "frac": round(ach / entry["peak"], 4), "traffic": traffic, "traffic_source": tnote, "peak_note": entry["note"],
-            "achieved_over_fp32_mfma_peak_157TF": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "kernel": entry["kernel"],
+            "achieved_over_fp32_mfma_peak_157TF": round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
+            "achieved_over_bf16x6_ceiling_416.7TF": round(ach / BF16X6_PEAK, 4), "kernel": entry["kernel"],
             "avg_launch_ms": round(k_ms / n, 4), "launches_timed": n,
             "algorithmic_flops_per_launch": flops / n, "algorithmic_bytes_per_launch": byts / n,
             "hbm_achieved_GBs": round(byts / (k_ms * 1e-3) / 1e9, 1),
@@ -435,7 +441,9 @@ def main():
                            "batch_per_gpu": args.batch, "global_batch": args.batch * world, "clip_len": T,
                            "optimizer": "torch.optim.Adam" if args.torch_adam else "fused flat Adam (wm_adam_step)",
                            "conv_arithmetic": ("64->64 convs (k3 and k7: fwd, dgrad, wgrad) and the LSTM input projection: bf16x6 split on "
-                                               "bf16 MFMA, fp32 accumulate (2.7e-7 vs fp64; native fp32 MFMA 2.5e-7)")
+                                               "bf16 MFMA, fp32 accumulate (2.7e-7 vs fp64; native fp32 MFMA 2.5e-7); ResBlock backward "
+                                               "(data + weight gradients): f16 two-piece split, three products, fp32 accumulate "
+                                               "(within 2e-6 of the bf16x6 gradients)")
                            if (args.model == "main16" and bf_mode) else "native fp32 MFMA",
                            "parallelism": f"dp{world}" if world > 1 else "single"},
                 "loss": round(r["loss"], 6), "roofline": r["roofline"]}
