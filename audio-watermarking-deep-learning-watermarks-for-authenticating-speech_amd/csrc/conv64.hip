@@ -872,9 +872,11 @@ __device__ __forceinline__ void lds_barrier() {          // s_barrier without dr
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-template <int PRO, int EPI, bool STATS>
+// H = true: the f16 two-piece build (pieces hi = f16(x), lo = f16(x - hi); three products lo hi, hi lo, hi hi on v_mfma_f32_32x32x16_f16;
+// weight image from wm_pack_w64_h: w * ws with ws a power of two, the accumulators are multiplied by 1 / ws in the epilogue)
+template <int PRO, int EPI, bool STATS, bool H = false>
 __global__ __launch_bounds__(256) void conv64bf3_kernel(Conv64Args a) {
-    constexpr int KW = 3, NT = 128, ROWS = NT + 2, PITCH = 72, NP = 3, NC = 4;
+    constexpr int KW = 3, NT = 128, ROWS = NT + 2, PITCH = 72, NP = H ? 2 : 3, NC = 4;
     constexpr int XBUF = NP * ROWS * PITCH;               // bf16 elements per input image
     constexpr bool TWO = (PRO == PRO_BNBWD);
     constexpr bool E1 = (EPI == EPI_RELUMASK || EPI == EPI_ADD || EPI == EPI_BNADDRELU);
@@ -888,7 +890,7 @@ __global__ __launch_bounds__(256) void conv64bf3_kernel(Conv64Args a) {
     const int tilesPerClip = (T + NT - 1) / NT, ntiles = a.B * tilesPerClip;
 
     // ---- resident weight fragments: packed image [NP][KW][64 out][64 in] bf16
-    bf16x8 Wr[12][NP];
+    u32x4 Wr[12][NP];
     {
         const uint4* wg = reinterpret_cast<const uint4*>(a.wp);
 #pragma unroll
@@ -902,9 +904,11 @@ __global__ __launch_bounds__(256) void conv64bf3_kernel(Conv64Args a) {
                 // allocator, the fragments beyond the VGPR budget are copied back (v_accvgpr_read) in front of their k-step
                 asm volatile("" : "+a"(w_));
 #endif
-                Wr[s][p] = __builtin_bit_cast(bf16x8, w_);
+                Wr[s][p] = w_;
             }
     }
+    const float winv = H ? reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(a.wp) + NP * KW * 4096)[1] : 1.f;
+    const float wsc = H ? reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(a.wp) + NP * KW * 4096)[0] : 1.f;
     // ---- staging map (fixed per thread): channel pair cp = 8*wave + (lane & 7), time quads q = 8*i + (lane >> 3)
     const int cp = wave * 8 + (lane & 7), c0 = 2 * cp, q0 = lane >> 3;
     const int hc = (tid & 127) >> 1, hh = tid & 1;
@@ -969,10 +973,16 @@ __global__ __launch_bounds__(256) void conv64bf3_kernel(Conv64Args a) {
             va = pro_apply<PRO>(va, wa, ka0, kb0, kc0, kl0);
             vb = pro_apply<PRO>(vb, wb, ka1, kb1, kc1, kl1);
         }
-        unsigned p0, p1, p2;
-        split3_pair(va, vb, p0, p1, p2);
         const int o = (1 + 4 * (q0 + 8 * i) + e) * (PITCH / 2) + cp;
-        X32[o] = p0; X32[(ROWS * PITCH >> 1) + o] = p1; X32[2 * (ROWS * PITCH >> 1) + o] = p2;
+        if (H) {
+            const h16x2 h_ = __builtin_convertvector(f32x2{va, vb}, h16x2);
+            const h16x2 l_ = __builtin_convertvector(f32x2{va - (float)h_.x, vb - (float)h_.y}, h16x2);
+            X32[o] = __builtin_bit_cast(unsigned, h_); X32[(ROWS * PITCH >> 1) + o] = __builtin_bit_cast(unsigned, l_);
+        } else {
+            unsigned p0, p1, p2;
+            split3_pair(va, vb, p0, p1, p2);
+            X32[o] = p0; X32[(ROWS * PITCH >> 1) + o] = p1; X32[2 * (ROWS * PITCH >> 1) + o] = p2;
+        }
     };
     auto split_halo = [&](unsigned short* X, int t0) {
         {                                             // threads 128..255 repeat the writes of 0..127 (no branch)
@@ -980,10 +990,16 @@ __global__ __launch_bounds__(256) void conv64bf3_kernel(Conv64Args a) {
             float v = hl;
             if (PRO != PRO_NONE) v = pro_apply<PRO>(v, hl2, ha, hb, hcc, hlo);
             if (t < 0 || t >= T) v = 0.f;
-            unsigned p0, p1, p2;
-            split3_pair(v, 0.f, p0, p1, p2);
             const int o = (hh ? NT + 1 : 0) * PITCH + hc;
-            X[o] = (unsigned short)p0; X[ROWS * PITCH + o] = (unsigned short)p1; X[2 * ROWS * PITCH + o] = (unsigned short)p2;
+            if (H) {
+                const _Float16 h_ = (_Float16)v;
+                const _Float16 l_ = (_Float16)(v - (float)h_);
+                X[o] = __builtin_bit_cast(unsigned short, h_); X[ROWS * PITCH + o] = __builtin_bit_cast(unsigned short, l_);
+            } else {
+                unsigned p0, p1, p2;
+                split3_pair(v, 0.f, p0, p1, p2);
+                X[o] = (unsigned short)p0; X[ROWS * PITCH + o] = (unsigned short)p1; X[2 * ROWS * PITCH + o] = (unsigned short)p2;
+            }
         }
     };
     // the same split in stages, one per scheduling slice of the main loop (WM_BF3_MANUAL)
@@ -1007,22 +1023,33 @@ __global__ __launch_bounds__(256) void conv64bf3_kernel(Conv64Args a) {
         asm volatile("" : "+v"(sva), "+v"(svb));
     };
     auto split_st1 = [&]() {
-        const bf16x2 hh_ = {(__bf16)sva, (__bf16)svb};
-        sp0 = __builtin_bit_cast(unsigned, hh_);
-        sva -= __uint_as_float(sp0 << 16); svb -= __uint_as_float(sp0 & 0xffff0000u);
+        if (H) {
+            const h16x2 hh_ = __builtin_convertvector(f32x2{sva, svb}, h16x2);
+            sp0 = __builtin_bit_cast(unsigned, hh_);
+            sva -= (float)hh_.x; svb -= (float)hh_.y;
+        } else {
+            const bf16x2 hh_ = {(__bf16)sva, (__bf16)svb};
+            sp0 = __builtin_bit_cast(unsigned, hh_);
+            sva -= __uint_as_float(sp0 << 16); svb -= __uint_as_float(sp0 & 0xffff0000u);
+        }
         asm volatile("" : "+v"(sva), "+v"(svb), "+v"(sp0));
     };
     auto split_st2 = [&]() {
+        if (H) return;                                   // two pieces: no middle one
         const bf16x2 mm_ = {(__bf16)sva, (__bf16)svb};
         sp1 = __builtin_bit_cast(unsigned, mm_);
         sva -= __uint_as_float(sp1 << 16); svb -= __uint_as_float(sp1 & 0xffff0000u);
         asm volatile("" : "+v"(sva), "+v"(svb), "+v"(sp1));
     };
-    auto split_out = [&](unsigned* X32, int i, int e) {
+    auto last_piece = [&]() -> unsigned {
+        if (H) return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{sva, svb}, h16x2));
         const bf16x2 ll_ = {(__bf16)sva, (__bf16)svb};
-        const unsigned sp2 = __builtin_bit_cast(unsigned, ll_);
+        return __builtin_bit_cast(unsigned, ll_);
+    };
+    auto split_out = [&](unsigned* X32, int i, int e) {
+        const unsigned sp2 = last_piece();
         const int o = (1 + 4 * (q0 + 8 * i) + e) * (PITCH / 2) + cp;
-        X32[o] = sp0; X32[(ROWS * PITCH >> 1) + o] = sp1; X32[2 * (ROWS * PITCH >> 1) + o] = sp2;
+        X32[o] = sp0; if (!H) X32[(ROWS * PITCH >> 1) + o] = sp1; X32[(NP - 1) * (ROWS * PITCH >> 1) + o] = sp2;
     };
     auto halo_pick = [&](int t0) {
         const int t = hh ? t0 + NT : t0 - 1;
@@ -1033,10 +1060,9 @@ __global__ __launch_bounds__(256) void conv64bf3_kernel(Conv64Args a) {
         asm volatile("" : "+v"(sva), "+v"(svb));
     };
     auto halo_out = [&](unsigned short* X) {
-        const bf16x2 ll_ = {(__bf16)sva, (__bf16)svb};
-        const unsigned sp2 = __builtin_bit_cast(unsigned, ll_);
+        const unsigned sp2 = last_piece();
         const int o = (hh ? NT + 1 : 0) * PITCH + hc;
-        X[o] = (unsigned short)sp0; X[ROWS * PITCH + o] = (unsigned short)sp1; X[2 * ROWS * PITCH + o] = (unsigned short)sp2;
+        X[o] = (unsigned short)sp0; if (!H) X[ROWS * PITCH + o] = (unsigned short)sp1; X[(NP - 1) * ROWS * PITCH + o] = (unsigned short)sp2;
     };
     {
         const int t0 = (min(tile, ntiles - 1) % tilesPerClip) * NT;
@@ -1080,7 +1106,7 @@ __global__ __launch_bounds__(256) void conv64bf3_kernel(Conv64Args a) {
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) accp[nt][r] = (EPI == EPI_BIAS) ? -kbias[r] : 0.f;
+        for (int r = 0; r < 16; ++r) accp[nt][r] = (EPI == EPI_BIAS) ? -kbias[r] * wsc : 0.f;       // wsc: a power of two (exact)
     // output / epilogue-operand addressing through buffer descriptors over the wave's 32 channel rows of a clip: per-lane offset
     // = column, scalar offset = row (sixteen loop-invariant scalars), the column block nt as the immediate -- one instruction per
     // value instead of a 64-bit scalar add, a 64-bit vector add and the access
@@ -1101,6 +1127,7 @@ __global__ __launch_bounds__(256) void conv64bf3_kernel(Conv64Args a) {
         const int nt = idx >> 4, r = idx & 15;
         float v = accp[nt][r];
         float q = 0.f;
+        if (H) v *= winv;                               // exact (power of two); contracts with the bias add
         if (EPI == EPI_BIAS) v += kbias[r];
         if (EPI == EPI_RELUMASK) { q = e1r[idx]; v = (fmaf(q, kea[r], keb[r]) > 0.f) ? v : 0.f; }
         if (EPI == EPI_ADD) v += e1r[idx];
@@ -1111,6 +1138,10 @@ __global__ __launch_bounds__(256) void conv64bf3_kernel(Conv64Args a) {
         if (STATS) asm volatile("" : "+v"(s1[r]), "+v"(s2[r]));
 #endif
         if (E1 && fetch) e1r[idx] = buf_load(se1c, vcolc + 128u * nt, rowT[r]);
+    };
+    auto mma = [&](const u32x4& A_, const u32x4& B_, f32x16 c) -> f32x16 {
+        if (H) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, A_), __builtin_bit_cast(h16x8, B_), c, 0, 0, 0);
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A_), __builtin_bit_cast(bf16x8, B_), c, 0, 0, 0);
     };
     while (tile < tend) {
         STAMP(ts0);
@@ -1128,9 +1159,9 @@ __global__ __launch_bounds__(256) void conv64bf3_kernel(Conv64Args a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
         const unsigned short* xrow = xcur + (64 * nh + l31) * PITCH + 8 * half;
-        bf16x8 Bq[2][NP];
+        u32x4 Bq[2][NP];
 #pragma unroll
-        for (int p = 0; p < NP; ++p) Bq[0][p] = *reinterpret_cast<const bf16x8*>(xrow + p * ROWS * PITCH);
+        for (int p = 0; p < NP; ++p) Bq[0][p] = *reinterpret_cast<const u32x4*>(xrow + p * ROWS * PITCH);
 #if WM_BF3_MANUAL
         // Hand-pinned schedule: every MFMA is followed by one slice of the side work (sched_barrier fences; the arithmetic of a
         // slice is tied to it by an empty asm on its results).  The six MFMAs of a half-step chain on one accumulator, each
@@ -1164,16 +1195,22 @@ __global__ __launch_bounds__(256) void conv64bf3_kernel(Conv64Args a) {
                 const int s1_ = (h + 1) >> 1, n1 = (h + 1) & 1;
 #pragma unroll
                 for (int p = 0; p < NP; ++p)
-                    Bq[(h + 1) & 1][p] = *reinterpret_cast<const bf16x8*>(xrow + (p * ROWS + 32 * n1 + (s1_ >> 2)) * PITCH + 16 * (s1_ & 3));
+                    Bq[(h + 1) & 1][p] = *reinterpret_cast<const u32x4*>(xrow + (p * ROWS + 32 * n1 + (s1_ >> 2)) * PITCH + 16 * (s1_ & 3));
             }
-            const bf16x8* Bf = Bq[h & 1];
+            const u32x4* Bf = Bq[h & 1];
             FENCE;
-            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wr[s][1], Bf[1], acc[nt], 0, 0, 0); FENCE; BF3_SLICE(0) FENCE;
-            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wr[s][0], Bf[2], acc[nt], 0, 0, 0); FENCE; BF3_SLICE(1) FENCE;
-            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wr[s][2], Bf[0], acc[nt], 0, 0, 0); FENCE; BF3_SLICE(2) FENCE;
-            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wr[s][0], Bf[1], acc[nt], 0, 0, 0); FENCE; BF3_SLICE(3) FENCE;
-            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wr[s][1], Bf[0], acc[nt], 0, 0, 0); FENCE; BF3_SLICE(4) FENCE;
-            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wr[s][0], Bf[0], acc[nt], 0, 0, 0); FENCE; BF3_SLICE(5) FENCE;
+            if (H) {                                     // lo hi, hi lo, hi hi: two slices behind every MFMA
+                acc[nt] = mma(Wr[s][1], Bf[0], acc[nt]); FENCE; BF3_SLICE(0) FENCE; BF3_SLICE(1) FENCE;
+                acc[nt] = mma(Wr[s][0], Bf[1], acc[nt]); FENCE; BF3_SLICE(3) FENCE; BF3_SLICE(4) FENCE;
+                acc[nt] = mma(Wr[s][0], Bf[0], acc[nt]); FENCE; BF3_SLICE(5) FENCE;
+            } else {
+                acc[nt] = mma(Wr[s][1], Bf[1], acc[nt]); FENCE; BF3_SLICE(0) FENCE;
+                acc[nt] = mma(Wr[s][0], Bf[2], acc[nt]); FENCE; BF3_SLICE(1) FENCE;
+                acc[nt] = mma(Wr[s][2], Bf[0], acc[nt]); FENCE; BF3_SLICE(2) FENCE;
+                acc[nt] = mma(Wr[s][0], Bf[1], acc[nt]); FENCE; BF3_SLICE(3) FENCE;
+                acc[nt] = mma(Wr[s][1], Bf[0], acc[nt]); FENCE; BF3_SLICE(4) FENCE;
+                acc[nt] = mma(Wr[s][0], Bf[0], acc[nt]); FENCE; BF3_SLICE(5) FENCE;
+            }
 #ifdef WM_STAMP
 #ifdef WM_STAMP_FINE
             if (h == 16) { STAMP(tsa); tm[0] += tsa - ts0; }
@@ -1196,15 +1233,16 @@ __global__ __launch_bounds__(256) void conv64bf3_kernel(Conv64Args a) {
                 const int s1_ = (h + 1) >> 1, n1 = (h + 1) & 1;
 #pragma unroll
                 for (int p = 0; p < NP; ++p)
-                    Bq[(h + 1) & 1][p] = *reinterpret_cast<const bf16x8*>(xrow + (p * ROWS + 32 * n1 + (s1_ >> 2)) * PITCH + 16 * (s1_ & 3));
+                    Bq[(h + 1) & 1][p] = *reinterpret_cast<const u32x4*>(xrow + (p * ROWS + 32 * n1 + (s1_ >> 2)) * PITCH + 16 * (s1_ & 3));
             }
-            const bf16x8* Bf = Bq[h & 1];
-            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wr[s][1], Bf[1], acc[nt], 0, 0, 0);
-            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wr[s][0], Bf[2], acc[nt], 0, 0, 0);
-            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wr[s][2], Bf[0], acc[nt], 0, 0, 0);
-            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wr[s][0], Bf[1], acc[nt], 0, 0, 0);
-            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wr[s][1], Bf[0], acc[nt], 0, 0, 0);
-            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wr[s][0], Bf[0], acc[nt], 0, 0, 0);
+            const u32x4* Bf = Bq[h & 1];
+            static_assert(!H, "the f16 build exists in the hand-pinned schedule only");
+            acc[nt] = mma(Wr[s][1], Bf[1], acc[nt]);
+            acc[nt] = mma(Wr[s][0], Bf[2], acc[nt]);
+            acc[nt] = mma(Wr[s][2], Bf[0], acc[nt]);
+            acc[nt] = mma(Wr[s][0], Bf[1], acc[nt]);
+            acc[nt] = mma(Wr[s][1], Bf[0], acc[nt]);
+            acc[nt] = mma(Wr[s][0], Bf[0], acc[nt]);
             // side work of this half-step
             if (h < 16) {
                 split_unit(reinterpret_cast<unsigned*>(xnxt), nt0, h >> 2, h & 3);
@@ -1283,11 +1321,11 @@ __global__ __launch_bounds__(256) void conv64bf3_kernel(Conv64Args a) {
     }
 }
 
-template <int PRO, int EPI, bool STATS>
+template <int PRO, int EPI, bool STATS, bool H = false>
 int launch_conv64bf3(const Conv64Args& a, hipStream_t stream) {
-    constexpr size_t lds = (size_t)(2 * 3 * 130 * 72) * 2 + 6 * 64 * sizeof(float);
+    constexpr size_t lds = (size_t)(2 * (H ? 2 : 3) * 130 * 72) * 2 + 6 * 64 * sizeof(float);
     static wm::DevOnce attr_done;
-    auto kern = conv64bf3_kernel<PRO, EPI, STATS>;
+    auto kern = conv64bf3_kernel<PRO, EPI, STATS, H>;
     if (!wm::dev_done(attr_done)) {
         WM_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         wm::dev_mark(attr_done);
@@ -3778,10 +3816,19 @@ int wm_set_conv_bf_schedule(int schedule, hipStream_t) { g_bf_schedule = (schedu
 
 int wm_conv64_bf(const float* x, const float* x2, const void* wpb, const float* pa, const float* pb, const float* pc,
                  const float* bias, const float* e1, const float* ea, const float* eb, float* y, float* stats,
-                 int B, int T, int pro, int epi, hipStream_t stream) {
+                 int B, int T, int pro, int epi, int arith, hipStream_t stream) {
     if (B <= 0 || T <= 0 || (T & 3)) return (int)hipErrorInvalidValue;
     Conv64Args a{x, x2, reinterpret_cast<const float*>(wpb), pa, pb, pc, bias, e1, ea, eb, y, stats, B, T};
     const bool st = stats != nullptr;
+    if (arith == 1) {                    // f16 two-piece split (wpb from wm_pack_w64_h): the forward convolutions of the pipelined kernel only
+        if (g_bf_schedule != 2 || (T & 127)) return (int)hipErrorInvalidValue;
+        if (pro == PRO_BNRELU && epi == EPI_BNADDRELU && !st) return launch_conv64bf3<PRO_BNRELU, EPI_BNADDRELU, false, true>(a, stream);
+        if (epi != EPI_BIAS) return (int)hipErrorInvalidValue;
+        if (pro == PRO_NONE) return st ? launch_conv64bf3<PRO_NONE, EPI_BIAS, true, true>(a, stream) : launch_conv64bf3<PRO_NONE, EPI_BIAS, false, true>(a, stream);
+        if (pro == PRO_BNRELU) return st ? launch_conv64bf3<PRO_BNRELU, EPI_BIAS, true, true>(a, stream) : launch_conv64bf3<PRO_BNRELU, EPI_BIAS, false, true>(a, stream);
+        return (int)hipErrorInvalidValue;
+    }
+    if (arith != 0) return (int)hipErrorInvalidValue;
     if (pro == PRO_NONE && !st) {        // main14b_2's 64-channel blocks (no BatchNorm): the phase-serial kernel, any T % 4 == 0
         if (epi == EPI_BIASELU) return launch_conv64bf<PRO_NONE, EPI_BIASELU, false>(a, stream);
         if (epi == EPI_BIASADDELU) return launch_conv64bf<PRO_NONE, EPI_BIASADDELU, false>(a, stream);

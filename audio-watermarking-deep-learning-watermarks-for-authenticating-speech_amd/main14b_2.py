@@ -47,7 +47,7 @@ def _c64_conv(x, w, mode, bias, e1, epi):
     B, _, L = x.shape
     y = torch.empty_like(x)
     lib.wm_conv64_bf(_p(x), None, _p(ops.pack_w64_bf(w, mode)), None, None, None, _p(bias), _p(e1), None, None, _p(y), None, B, L, 0, epi,
-                     _stream())
+                     0, _stream())
     return y
 
 

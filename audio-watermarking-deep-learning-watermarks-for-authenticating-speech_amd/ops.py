@@ -150,7 +150,8 @@ _CONV = {"bf16x6": _os.environ.get("WM_CONV_BF16X6", "1") == "1", "schedule": 2,
          "fused_bwd": _os.environ.get("WM_FUSED_BWD", "1") == "1",
          "mask_on_load": _os.environ.get("WM_MASK_ON_LOAD", "1") == "1",
          "pair_fold": _os.environ.get("WM_PAIR_FOLD", "1") == "1",
-         "bwd_f16x3": _os.environ.get("WM_BWD_F16X3", "1") == "1"}
+         "bwd_f16x3": _os.environ.get("WM_BWD_F16X3", "1") == "1",
+         "fwd_f16x3": _os.environ.get("WM_FWD_F16X3", "1") == "1"}
 
 
 def set_conv_bf_schedule(schedule: int):
@@ -184,6 +185,13 @@ def set_bwd_f16x3(on: bool):
     (half the matrix work of bf16x6; power-of-two scales from max |w| and max |A| max |dz| keep the operands in the f16 range),
     0 bf16x6 as in the forward.  WM_BWD_F16X3=0/1 sets the default."""
     _CONV["bwd_f16x3"] = bool(on)
+
+
+def set_fwd_f16x3(on: bool):
+    """ResBlock forward convolutions launched through wm_conv64_bf (schedule 2, T % 128 == 0): 1 (default) the f16 two-piece split
+    (three products per product instead of six; weights scaled by a power of two from max |w|, activations unscaled), 0 bf16x6.
+    WM_FWD_F16X3=0/1 sets the default.  The one-launch inference ResBlock (wm_resblock_eval_bf) is bf16x6 either way."""
+    _CONV["fwd_f16x3"] = bool(on)
 
 
 def pack_w64_h(w: torch.Tensor, mode: int) -> torch.Tensor:
@@ -224,8 +232,9 @@ def pack_w64_bf7(w: torch.Tensor, mode: int) -> torch.Tensor:
 def _conv3(x, x2, w, mode, pa, pb, pc, bias, e1, ea, eb, y, stats, B, T, pro, epi):
     """one k3 64->64 convolution launch in the selected arithmetic mode (mode: 0 forward, 1 data gradient)"""
     if _CONV["bf16x6"]:
-        lib.wm_conv64_bf(_p(x), _p(x2), _p(pack_w64_bf(w, mode)), _p(pa), _p(pb), _p(pc), _p(bias), _p(e1), _p(ea), _p(eb), _p(y),
-                         _p(stats), B, T, pro, epi, _stream())
+        h = (_CONV["fwd_f16x3"] and mode == 0 and (pro, epi) in ((0, 0), (1, 0), (1, 4)) and _CONV["schedule"] == 2 and T % 128 == 0)
+        lib.wm_conv64_bf(_p(x), _p(x2), _p(pack_w64_h(w, 0) if h else pack_w64_bf(w, mode)), _p(pa), _p(pb), _p(pc), _p(bias), _p(e1),
+                         _p(ea), _p(eb), _p(y), _p(stats), B, T, pro, epi, 1 if h else 0, _stream())
     else:
         lib.wm_conv64(_p(x), _p(x2), _p(pack_w64(w, 3, mode)), _p(pa), _p(pb), _p(pc), _p(bias), _p(e1), _p(ea), _p(eb), _p(y),
                       _p(stats), B, T, 3, pro, epi, _stream())

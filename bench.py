@@ -271,11 +271,17 @@ def kernel_timers(lib, model, mode, bf_mode, batch):
                                        lambda a: (2.0 * 64 * 64 * 3 * a[13] * a[12], 2.0 * 64 * a[13] * 4 * a[12])),
                      kernel="conv64_kernel<KW=3> forward (wm_conv64: native fp32 MFMA; BN+ReLU fused on load, BN sums in epilogue)",
                      peak=PEAK_FP32_MFMA_TFLOPS, note=FP32_NOTE, pmc=pmc16, pmc_prefixes=("conv64_kernel<3, 256",))]
+    fh = _ops._CONV["fwd_f16x3"] and _ops._CONV["schedule"] == 2     # forward arithmetic: f16 two-piece split | bf16x6
+    F16X3_NOTE = ("f16 dense MFMA peak 2500 TFLOP/s / 3 f16 piece products per product (the bf16x6 build of rounds 1-2 was priced "
+                  "against 2500 / 6 = 416.7)")
     fwd = dict(timer=LaunchTimer(lib, "wm_conv64_bf", lambda a: a[15] == 0,
                                  lambda a: (2.0 * 64 * 64 * 3 * a[13] * a[12], 2.0 * 64 * a[13] * 4 * a[12])),
-               kernel="conv64bf3_kernel forward (wm_conv64_bf, epilogue = bias: Conv1d(64,64,3) as bf16x6 split products on the bf16 matrix "
-                      "cores, fp32 accumulate, fp32-grade error; BN+ReLU fused on load, BN sums in the epilogue)",
-               peak=BF16X6_PEAK, note=BF16X6_NOTE, pmc=pmc16, pmc_prefixes=("conv64bf3_kernel<0, 0", "conv64bf3_kernel<1, 0"))
+               kernel="conv64bf3_kernel forward (wm_conv64_bf, epilogue = bias: Conv1d(64,64,3) as " +
+                      ("f16 two-piece split, three piece products per product on v_mfma_f32_32x32x16_f16" if fh else
+                       "bf16x6 split products on the bf16 matrix cores") +
+                      ", fp32 accumulate, fp32-grade error; BN+ReLU fused on load, BN sums in the epilogue)",
+               peak=(PEAK_BF16_MFMA_TFLOPS / 3.0) if fh else BF16X6_PEAK, note=F16X3_NOTE if fh else BF16X6_NOTE, pmc=pmc16,
+               pmc_prefixes=("conv64bf3_kernel<0, 0", "conv64bf3_kernel<1, 0"))
     if mode == "fwd":
         if not _ops._CONV["one_launch_eval"]:
             return [fwd]
@@ -299,8 +305,7 @@ def kernel_timers(lib, model, mode, bf_mode, batch):
                      "in the epilogue; " + ("f16 two-piece split, three piece products per product on v_mfma_f32_32x32x16_f16" if h else
                                             "bf16x6 split products") + ", fp32 accumulate; the largest share of the step's kernel time)",
               peak=(PEAK_BF16_MFMA_TFLOPS / 3.0) if h else BF16X6_PEAK,
-              note=("f16 dense MFMA peak 2500 TFLOP/s / 3 f16 piece products per product (the bf16x6 build of rounds 1-2 was priced "
-                    "against 2500 / 6 = 416.7)") if h else BF16X6_NOTE,
+              note=F16X3_NOTE if h else BF16X6_NOTE,
               pmc=pmc16, pmc_prefixes=("dwgrad64bf_kernel<",))
     return [dw, fwd]
 

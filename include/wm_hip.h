@@ -64,7 +64,12 @@ int wm_pack_w64_bf(const float* w, void* wpb, int mode, wm_stream_t stream);
 int wm_set_conv_bf_schedule(int schedule, wm_stream_t stream);
 int wm_conv64_bf(const float* x, const float* x2, const void* wpb, const float* pa, const float* pb, const float* pc,
                  const float* bias, const float* e1, const float* ea, const float* eb, float* y, float* stats,
-                 int B, int T, int pro, int epi, wm_stream_t stream);
+                 int B, int T, int pro, int epi, int arith, wm_stream_t stream);
+/* arith 0: bf16x6, wpb from wm_pack_w64_bf.  arith 1: f16 two-piece split, three products per product on v_mfma_f32_32x32x16_f16
+ * (see wm_dwgrad64_bf below), wpb from wm_pack_w64_h(mode 0); only (pro 0 | 1, epi 0, with or without stats) and (pro 1, epi 4) under
+ * schedule 2 with T % 128 == 0 -- the ResBlock forward convolutions -- hipErrorInvalidValue otherwise.  Activations are split unscaled: the
+ * representation floor is 2^-25 ABSOLUTE (f16 subnormal spacing / 2) on top of 2^-22 relative, i.e. fp32-grade for the O(1)
+ * activations BatchNorm + ReLU produce. */
 
 /* Inference ResBlock as ONE launch (py/main16.py:112-125 with both BatchNorm1d in eval mode):
  *   y = relu(x + (conv2(relu((conv1(x) + b1) * sc1 + sh1)) + b2) * sc2 + sh2)
@@ -95,7 +100,7 @@ int wm_dwgrad64_bf(const float* g, const float* g2, const float* ga, const float
                    const void* gmask, int arith, const float* gscale, float* dzmax, wm_stream_t stream);
 /* arith 0: bf16 three-piece split, six piece products (bf16x6); wpb from wm_pack_w64_bf.
  * arith 1: f16 TWO-piece split (22 bits per operand), three products on v_mfma_f32_32x32x16_f16 -- half the matrix work of arith 0,
- *          used for the BACKWARD only (gradient tolerance; the forward stays bf16x6).  wpb from wm_pack_w64_h (weights scaled by a
+ *          wpb from wm_pack_w64_h (weights scaled by a
  *          power of two chosen from max |w|, stored behind the image); gscale = wm_bn_bwd_finalize's {gs, 1 / gs} for THIS launch's
  *          g; dzmax (optional, epi 1 / 8): 256 floats, max |y| per workgroup = the dzmax input of the next launch's finalize. */
 int wm_pack_w64_h(const float* w, void* wph, int mode, wm_stream_t stream);      /* 2 * 3 * 4096 f16 + 2 floats */

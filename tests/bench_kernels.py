@@ -42,17 +42,17 @@ timeit("conv64 k3 fwd bnrelu/bias +stats", lambda: lib.wm_conv64(_p(x), None, _p
 timeit("conv64 k3 dgrad bnbwd/relumask +stats", lambda: lib.wm_conv64(_p(x), _p(x2), _p(wp3), _p(c[0]), _p(c[1]), _p(c[2]), None, _p(x3), _p(c[3]), _p(c[4]), _p(y), _p(stats), B, T, 3, 3, 1, st), F3, 4 * FR)
 timeit("conv64 k3 dgrad bnbwd/add", lambda: lib.wm_conv64(_p(x), _p(x2), _p(wp3), _p(c[0]), _p(c[1]), _p(c[2]), None, _p(x3), None, None, _p(y), None, B, T, 3, 3, 2, st), F3, 4 * FR)
 wpb = ops.pack_w64_bf(w3, 0)
-timeit("conv64bf k3 fwd none/bias", lambda: lib.wm_conv64_bf(_p(x), None, _p(wpb), None, None, None, _p(bias), None, None, None, _p(y), None, B, T, 0, 0, st), F3, 2 * FR)
-timeit("conv64bf k3 fwd none/bias +stats", lambda: lib.wm_conv64_bf(_p(x), None, _p(wpb), None, None, None, _p(bias), None, None, None, _p(y), _p(stats), B, T, 0, 0, st), F3, 2 * FR)
-timeit("conv64bf k3 fwd bnrelu/bias +stats", lambda: lib.wm_conv64_bf(_p(x), None, _p(wpb), _p(c[0]), _p(c[1]), None, _p(bias), None, None, None, _p(y), _p(stats), B, T, 1, 0, st), F3, 2 * FR)
-timeit("conv64bf k3 dgrad bnbwd/relumask +stats", lambda: lib.wm_conv64_bf(_p(x), _p(x2), _p(wpb), _p(c[0]), _p(c[1]), _p(c[2]), None, _p(x3), _p(c[3]), _p(c[4]), _p(y), _p(stats), B, T, 3, 1, st), F3, 4 * FR)
-timeit("conv64bf k3 dgrad bnbwd/add", lambda: lib.wm_conv64_bf(_p(x), _p(x2), _p(wpb), _p(c[0]), _p(c[1]), _p(c[2]), None, _p(x3), None, None, _p(y), None, B, T, 3, 2, st), F3, 4 * FR)
+timeit("conv64bf k3 fwd none/bias", lambda: lib.wm_conv64_bf(_p(x), None, _p(wpb), None, None, None, _p(bias), None, None, None, _p(y), None, B, T, 0, 0, 0, st), F3, 2 * FR)
+timeit("conv64bf k3 fwd none/bias +stats", lambda: lib.wm_conv64_bf(_p(x), None, _p(wpb), None, None, None, _p(bias), None, None, None, _p(y), _p(stats), B, T, 0, 0, 0, st), F3, 2 * FR)
+timeit("conv64bf k3 fwd bnrelu/bias +stats", lambda: lib.wm_conv64_bf(_p(x), None, _p(wpb), _p(c[0]), _p(c[1]), None, _p(bias), None, None, None, _p(y), _p(stats), B, T, 1, 0, 0, st), F3, 2 * FR)
+timeit("conv64bf k3 dgrad bnbwd/relumask +stats", lambda: lib.wm_conv64_bf(_p(x), _p(x2), _p(wpb), _p(c[0]), _p(c[1]), _p(c[2]), None, _p(x3), _p(c[3]), _p(c[4]), _p(y), _p(stats), B, T, 3, 1, 0, st), F3, 4 * FR)
+timeit("conv64bf k3 dgrad bnbwd/add", lambda: lib.wm_conv64_bf(_p(x), _p(x2), _p(wpb), _p(c[0]), _p(c[1]), _p(c[2]), None, _p(x3), None, None, _p(y), None, B, T, 3, 2, 0, st), F3, 4 * FR)
 if not only or "acc" in only:
     # accuracy of both arithmetic modes against fp64 on one clip
     xs = x[:2].double().cpu(); ref = torch.nn.functional.conv1d(xs, w3.double().cpu(), bias.double().cpu(), padding=1)
     y1_ = torch.empty_like(x[:2]); y2_ = torch.empty_like(x[:2])
     lib.wm_conv64(_p(x[:2].contiguous()), None, _p(wp3), None, None, None, _p(bias), None, None, None, _p(y1_), None, 2, T, 3, 0, 0, st)
-    lib.wm_conv64_bf(_p(x[:2].contiguous()), None, _p(wpb), None, None, None, _p(bias), None, None, None, _p(y2_), None, 2, T, 0, 0, st)
+    lib.wm_conv64_bf(_p(x[:2].contiguous()), None, _p(wpb), None, None, None, _p(bias), None, None, None, _p(y2_), None, 2, T, 0, 0, 0, st)
     cpu32 = torch.nn.functional.conv1d(x[:2].cpu(), w3.cpu(), bias.cpu(), padding=1)
     sc = float(ref.abs().max())
     print(f"acc vs fp64 (max abs / max|ref|): native fp32 MFMA {float((y1_.double().cpu()-ref).abs().max())/sc:.2e}   bf16x6 {float((y2_.double().cpu()-ref).abs().max())/sc:.2e}   torch CPU fp32 {float((cpu32.double()-ref).abs().max())/sc:.2e}")
@@ -70,6 +70,10 @@ timeit("wgrad64bf7 k7 none x addvec", lambda: lib.wm_wgrad64_bf7(_p(x), _p(x2), 
 timeit("bn_add_relu", lambda: lib.wm_bn_add_relu(_p(x), _p(x2), _p(c[0]), _p(c[1]), _p(y), B, T, st), None, 3 * FR)
 part = _f32(B * 128, device=dev)
 timeit("relu_bwd_reduce", lambda: lib.wm_relu_bwd_reduce(_p(x), _p(x2), _p(x3), _p(y), _p(part), B, T, st), None, 4 * FR)
+mask = torch.empty(B * 64 * ((T + 31) // 32), dtype=torch.int32, device=dev)
+dzmax = _f32(B * 64, device=dev)
+timeit("bn_add_relu_mask", lambda: lib.wm_bn_add_relu_mask(_p(x), _p(x2), _p(c[0]), _p(c[1]), _p(y), _p(mask), B, T, st), None, 3 * FR + mask.numel() * 4)
+timeit("relu_bwd_reduce_mask sums only", lambda: lib.wm_relu_bwd_reduce_mask(_p(x), _p(mask), _p(x3), None, _p(part), _p(dzmax), B, T, st), None, 2 * FR + mask.numel() * 4)
 # LSTM
 wi = torch.randn(256, 64, device=dev) * 0.1; wh = torch.randn(256, 64, device=dev) * 0.1
 bi = torch.randn(256, device=dev) * 0.1

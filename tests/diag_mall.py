@@ -42,7 +42,7 @@ def main():
     def dgrad(b0, n):
         o = b0 * 64 * T * 4
         lib.wm_conv64_bf(p(dz) + o, p(y2) + o, p(wp), p(k[0]), p(k[1]), p(k[3]), None, p(y1) + o, p(sc), p(sh), p(out) + o, p(stats),
-                         n, T, 3, 1, st)
+                         n, T, 3, 1, 0, st)
 
     def wgrad(b0, n, acc):
         o = b0 * 64 * T * 4

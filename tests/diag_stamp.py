@@ -14,11 +14,16 @@ L.wm_debug_set_stamp_buffer(vp(buf.data_ptr()))
 L.wm_pack_w64(vp(w.data_ptr()), vp(wp.data_ptr()), 3, 0, None)
 wpb = torch.empty(3 * 3 * 4096, dtype=torch.int16, device=dev)
 L.wm_pack_w64_bf(vp(w.data_ptr()), vp(wpb.data_ptr()), 0, None)
+ARITH = int(os.environ.get("WM_DIAG_ARITH", "0"))      # 1: the f16 two-piece build of the forward variants
+wph = torch.empty(2 * 3 * 4096 + 4, dtype=torch.int16, device=dev)
+L.wm_pack_w64_h(vp(w.data_ptr()), vp(wph.data_ptr()), 0, None)
+def HARITH(pro, epi):
+    return ARITH if pro in (0, 1) and epi == 0 else 0
 def run_bf(name, pro, epi, st):
-    args = [vp(x.data_ptr()), vp(x2.data_ptr()) if pro == 3 else None, vp(wpb.data_ptr()),
+    args = [vp(x.data_ptr()), vp(x2.data_ptr()) if pro == 3 else None, vp((wph if HARITH(pro, epi) else wpb).data_ptr()),
             vp(c[0].data_ptr()), vp(c[1].data_ptr()), vp(c[2].data_ptr()), vp(bias.data_ptr()),
             vp(x3.data_ptr()) if epi in (1, 2) else None, vp(c[3].data_ptr()), vp(c[4].data_ptr()), vp(y.data_ptr()),
-            vp(stats.data_ptr()) if st else None, B, T, pro, epi, None]
+            vp(stats.data_ptr()) if st else None, B, T, pro, epi, HARITH(pro, epi), None]
     for _ in range(2):
         buf.zero_(); rc = L.wm_conv64_bf(*args); torch.cuda.synchronize()
     assert rc == 0, rc
@@ -39,10 +44,10 @@ def run(name, pro, epi, st):
 if len(sys.argv) > 1:
     L.wm_set_conv_bf_schedule(2, None)
     def run_bf3(name, pro, epi, st):
-        args = [vp(x.data_ptr()), vp(x2.data_ptr()) if pro == 3 else None, vp(wpb.data_ptr()),
+        args = [vp(x.data_ptr()), vp(x2.data_ptr()) if pro == 3 else None, vp((wph if HARITH(pro, epi) else wpb).data_ptr()),
                 vp(c[0].data_ptr()), vp(c[1].data_ptr()), vp(c[2].data_ptr()), vp(bias.data_ptr()),
                 vp(x3.data_ptr()) if epi in (1, 2) else None, vp(c[3].data_ptr()), vp(c[4].data_ptr()), vp(y.data_ptr()),
-                vp(stats.data_ptr()) if st else None, B, T, pro, epi, None]
+                vp(stats.data_ptr()) if st else None, B, T, pro, epi, HARITH(pro, epi), None]
         e0, e1 = torch.cuda.Event(True), torch.cuda.Event(True)
         for _ in range(2):
             buf.zero_(); torch.cuda.synchronize(); e0.record(); rc = L.wm_conv64_bf(*args); e1.record(); torch.cuda.synchronize()

@@ -1002,10 +1002,47 @@ def test_conv_bf16x6_is_fp32_grade(awm, dev):
     xd, wd, bd = x.to(dev), w.to(dev), b.to(dev)
     y_n, y_b = torch.empty_like(xd), torch.empty_like(xd)
     lib.wm_conv64(_p(xd), None, _p(ops.pack_w64(wd, 3, 0)), None, None, None, _p(bd), None, None, None, _p(y_n), None, 2, 4000, 3, 0, 0, _stream())
-    lib.wm_conv64_bf(_p(xd), None, _p(ops.pack_w64_bf(wd, 0)), None, None, None, _p(bd), None, None, None, _p(y_b), None, 2, 4000, 0, 0, _stream())
+    lib.wm_conv64_bf(_p(xd), None, _p(ops.pack_w64_bf(wd, 0)), None, None, None, _p(bd), None, None, None, _p(y_b), None, 2, 4000, 0, 0, 0, _stream())
     e_n, e_b = rel_err(y_n, ref), rel_err(y_b, ref)
     print("native", e_n, "bf16x6", e_b)
     assert e_n < 1e-6 and e_b < 1e-6 and e_b < 3 * e_n + 1e-7
+
+
+def test_conv_f16_split_forward_is_fp32_grade(awm, dev):
+    """the f16 two-piece build of the pipelined k3 forward convolution (wm_conv64_bf arith 1: three products per product, weights scaled
+    by a power of two, activations unscaled) against fp64, beside bf16x6 (arith 0) on the same inputs -- plain and with BatchNorm + ReLU
+    applied on load and the BatchNorm sums in the epilogue; weight scales 1e-3 ... 10, activation scales 1e-2 ... 30.  Tolerance: the
+    error relative to max |y| stays below 1e-6 and within 3x of bf16x6's + 2e-7 (both are accumulation-dominated)."""
+    from awm_amd import ops
+    from awm_amd.ops import _p, _stream, lib
+    B, T = 3, 4096
+    for k, (ws, xs) in enumerate(((0.1, 1.0), (1e-3, 1.0), (10.0, 1.0), (0.1, 1e-2), (0.1, 30.0))):
+        x, w, b = rnd(B, 64, T, seed=10 + k, scale=xs), rnd(64, 64, 3, seed=20 + k, scale=ws), rnd(64, seed=30 + k)
+        sc, sh = 1.0 + 0.2 * rnd(64, seed=40 + k), 0.3 * rnd(64, seed=50 + k) * xs
+        xd, wd, bd, scd, shd = (t.to(dev) for t in (x, w, b, sc, sh))
+        for pro in (0, 1):
+            xin = torch.relu(x.double() * sc.double()[None, :, None] + sh.double()[None, :, None]) if pro else x.double()
+            ref = F.conv1d(xin, w.double(), b.double(), padding=1)
+            ys, sts = [], []
+            for arith in (0, 1):
+                y, st = torch.empty_like(xd), torch.zeros(256 * 128, device=dev)
+                wp = ops.pack_w64_h(wd, 0) if arith else ops.pack_w64_bf(wd, 0)
+                lib.wm_conv64_bf(_p(xd), None, _p(wp), _p(scd) if pro else None, _p(shd) if pro else None, None, _p(bd), None, None, None,
+                                 _p(y), _p(st), B, T, pro, 0, arith, _stream())
+                ys.append(y); sts.append(st.view(256, 2, 64).sum(0).double().cpu())
+            e_b, e_h = rel_err(ys[0], ref), rel_err(ys[1], ref)
+            print(f"w {ws} x {xs} pro {pro}: bf16x6 {e_b:.2e} f16 {e_h:.2e}")
+            assert e_h < 1e-6 and e_h < 3 * e_b + 2e-7, (ws, xs, pro, e_b, e_h)
+            s1, s2 = ref.sum((0, 2)), (ref * ref).sum((0, 2))          # the BatchNorm sums of the epilogue
+            assert float((sts[1][0] - s1).abs().max()) <= 2e-5 * float(s2.max().sqrt() * (B * T) ** 0.5) + 1e-3
+            assert float(((sts[1][1] - s2) / s2).abs().max()) < 2e-5
+    # refused outside its domain (the wrapper raises on a non-zero return): the phase-serial schedule's sizes, other epilogues
+    y = torch.empty(1, 64, 4000, device=dev)
+    with pytest.raises(RuntimeError):
+        lib.wm_conv64_bf(_p(y), None, _p(ops.pack_w64_h(wd, 0)), None, None, None, _p(bd), None, None, None, _p(y), None, 1, 4000, 0, 0, 1, _stream())
+    y = torch.empty(1, 64, 4096, device=dev)
+    with pytest.raises(RuntimeError):
+        lib.wm_conv64_bf(_p(y), None, _p(ops.pack_w64_h(wd, 0)), None, None, None, None, _p(y), None, None, _p(y), None, 1, 4096, 0, 2, 1, _stream())
 
 
 # ------------------------------------------------------------------------------------------ full-size properties
