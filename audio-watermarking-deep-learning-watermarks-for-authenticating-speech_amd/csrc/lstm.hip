@@ -582,6 +582,190 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(float* __restrict__ gates
 #endif
 }
 
+// ------------------------------------------------ recurrence bwd with the weight gradients beside it
+// Wave-specialised BPTT.  Waves 0..3 run lstm_bwd_kernel's recurrence unchanged (one clip per workgroup, one barrier per step); waves
+// 4..7 -- a second wave on each SIMD, whose matrix cores the recurrence never touches -- form the clip's weight gradients
+//   dW_ih[n'][c] = sum_t da[t][n'] x[t][c],   dW_hh[n'][k] = sum_t da[t][n'] h[t-1][k]
+// out of the 32-step chunk of da the recurrence finished LAST, while it walks the next one: da never has to be read back from HBM
+// for them (lstm_wgrad_bf_kernel: 4.2 GB at B = 256, and its A fragments -- 8 consecutive steps of one gate column -- were gathered
+// with ds_read_u16 from a [step][n'] image).  Here the recurrence lane that owns gate column n' drops its eight da values of an
+// 8-step block as two ds_write_b128 into a [n'][step] fp32 image (double-buffered by chunk); a helper lane reads 8 consecutive steps
+// of one column = one A fragment, splits it in registers (bf16x6) and multiplies it with B fragments that come straight from global
+// memory (x and h are [B,64,T]: 8 consecutive steps of one channel are contiguous).  Helper wave w owns gate columns [64 w, 64 w + 64)
+// for all 128 z rows (128 accumulator registers), 96 MFMAs per chunk = 3 per step.  Helpers execute the recurrence's barrier once
+// per step (s_barrier counts every wave of the workgroup) with a 1/32 slice of a chunk's work in between, so they can never run
+// behind; the recurrence keeps issue priority (s_setprio 3).  Per-clip slab: [256 n'][128 z] + [256] bias sums (the recurrence lanes
+// add their own da), reduced by lstm_wgrad_reduce_kernel.  T % 32 == 0.
+__global__ __launch_bounds__(512) void lstm_bwd_ws_kernel(float* __restrict__ gates, const float* __restrict__ cst,
+                                                          const float* __restrict__ dh_out, const float* __restrict__ w_hh,
+                                                          const float* __restrict__ x, const float* __restrict__ hseq,
+                                                          float* __restrict__ partial, int T) {
+    constexpr int CT = 32, PT = 36;                 // chunk length, fp32 pitch of one gate column's chunk (16-byte multiple)
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    float* daT = reinterpret_cast<float*>(smem_raw);                      // [2][256][PT]
+    float (*part)[64][4] = reinterpret_cast<float (*)[64][4]>(daT + 2 * 256 * PT);     // [2][64][4] partial dh
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float* out = partial + (size_t)b * (256 * 128 + 256);
+    if (wave < 4) {
+        // ------------------------------------------------------------------ the recurrence (lstm_bwd_kernel)
+        __builtin_amdgcn_s_setprio(3);
+        const int q = lane & 3, ul = lane >> 2, u = wave * 16 + ul, np = wave * 64 + lane;
+        float wt[64];
+#pragma unroll
+        for (int j = 0; j < 64; ++j) wt[j] = w_hh[((j & 3) * 64 + wave * 16 + (j >> 2)) * 64 + lane];
+        if (tid < 512 / 4) reinterpret_cast<float4*>(&part[0][0][0])[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+        float dc = 0.f, dbs = 0.f;
+        const wm_srd_t sgb = make_srd(gates + (size_t)b * T * 256, (size_t)T * 256 * sizeof(float));
+        const wm_srd_t scb = make_srd(cst + (size_t)b * T * 64, (size_t)T * 64 * sizeof(float));
+        const wm_srd_t sdh = make_srd(dh_out + (size_t)b * 64 * T, (size_t)64 * T * sizeof(float));
+        const unsigned vgb = (unsigned)np * 4u, vcb = (unsigned)u * 4u, vdh = (unsigned)(u * T) * 4u;
+        constexpr int CH = 8;
+        struct Buf { float ga[CH], cc[CH + 1], dh[CH]; };
+        Buf A, Bf;
+        auto prefetch = [&](Buf& f, int t1) {
+#pragma unroll
+            for (int j = 0; j < CH; ++j) {
+                const int t = max(t1 - CH + 1 + j, 0);
+                f.ga[j] = buf_load(sgb, vgb, (unsigned)t * 1024u);
+                f.dh[j] = buf_load(sdh, vdh, (unsigned)t * 4u);
+            }
+#pragma unroll
+            for (int j = 0; j <= CH; ++j) f.cc[j] = buf_load(scb, vcb, (unsigned)max(t1 - CH + j, 0) * 256u);
+        };
+        const bool is0 = q == 0, is1 = q == 1, is2 = q == 2, is3 = q == 3;
+        int pb = 0;
+        auto run_chunk = [&](const Buf& f, int t1) {            // t1 % 8 == 7, t1 >= 7 (T % 16 == 0)
+            float dav[CH];
+#pragma unroll
+            for (int jj = 0; jj < CH; ++jj) {
+                const int j = CH - 1 - jj, t = t1 - jj;
+                const float4 p = *reinterpret_cast<const float4*>(&part[pb][u][0]);
+                const float act = f.ga[j];
+                const float gi = quad_bcast<0>(act), gf = quad_bcast<1>(act), gg = quad_bcast<2>(act), go = quad_bcast<3>(act);
+                const float tc = tanh_s(f.cc[j + 1]);
+                const float cprev = (t >= 1) ? f.cc[j] : 0.f;
+                const float S = is0 ? gg : (is1 ? cprev : (is2 ? gi : tc));
+                const float D = is2 ? fmaf(-act, act, 1.f) : act * (1.f - act);
+                const float M = S * D;
+                const float K = go * fmaf(-tc, tc, 1.f);
+                const float dht = f.dh[j] + ((p.x + p.y) + (p.z + p.w));
+                const float dct = fmaf(dht, K, dc);
+                const float da = (is3 ? dht : dct) * M;
+                dc = dct * gf;
+                dav[j] = da;
+                buf_store(sgb, da, vgb, (unsigned)t * 1024u);
+                float Dd[4];
+                rows_replicate(da, Dd);
+                const float psum = dot64_rowbcast(Dd, wt);
+                part[pb ^ 1][lane][wave] = psum;
+                pb ^= 1;
+                if (jj == CH - 1) {                              // the block's eight values, oldest step first: [n'][t % 32 ...]
+                    const int t0 = t1 - (CH - 1);
+                    float* d = daT + (((t0 >> 5) & 1) * 256 + np) * PT + (t0 & (CT - 1));
+                    *reinterpret_cast<float4*>(d) = make_float4(dav[0], dav[1], dav[2], dav[3]);
+                    *reinterpret_cast<float4*>(d + 4) = make_float4(dav[4], dav[5], dav[6], dav[7]);
+                }
+                dbs += da;
+                __syncthreads();
+            }
+        };
+        prefetch(A, T - 1);
+        __syncthreads();
+        for (int t1 = T - 1; t1 >= 0; t1 -= 2 * CH) {
+            prefetch(Bf, t1 - CH);
+            run_chunk(A, t1);
+            prefetch(A, t1 - 2 * CH);
+            run_chunk(Bf, t1 - CH);
+        }
+        out[256 * 128 + np] = dbs;
+        return;
+    }
+    // ---------------------------------------------------------------------- the helpers: weight gradients of the finished chunk
+    const int hw = wave - 4, half = lane >> 5, l31 = lane & 31;
+    f32x16 acc[2][2][2];                           // [z: x | h][row tile of the wave's 64 gate columns][column tile of 64 channels]
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i >> 2][(i >> 1) & 1][i & 1][r] = 0.f;
+    const wm_srd_t sx = make_srd(x + (size_t)b * 64 * T, (size_t)64 * T * sizeof(float));
+    const wm_srd_t sh = make_srd(hseq + (size_t)b * 64 * T, (size_t)64 * T * sizeof(float));
+    // unit u of a chunk = (ks = u >> 2, z = (u >> 1) & 1, ct = u & 1): the B fragment (z, ct, ks) against both row tiles' A fragments
+    // of k-step ks.  Raw operands of unit u + 1 are fetched while unit u multiplies.
+    float raw[8];
+    auto load_raw = [&](int chunk, int u_) {       // chunk, u_ wave-uniform: the step rides in the scalar offset
+        const int ks = u_ >> 2, z = (u_ >> 1) & 1, ct = u_ & 1;
+        const unsigned v = (unsigned)((32 * ct + l31) * T + 8 * half) * 4u;
+        const int ts = chunk * CT + 16 * ks;
+        if (z == 0) {
+            const f32x4 a0 = buf_load4(sx, v, (unsigned)ts * 4u), a1 = buf_load4(sx, v, (unsigned)(ts + 4) * 4u);
+            raw[0] = a0[0]; raw[1] = a0[1]; raw[2] = a0[2]; raw[3] = a0[3]; raw[4] = a1[0]; raw[5] = a1[1]; raw[6] = a1[2]; raw[7] = a1[3];
+        } else {                                    // h[t - 1]: one step earlier (not 16-byte aligned), zero initial state
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int te = ts + e - 1;
+                // te = -1 (first step of the clip, wave-uniform): the upper half's lanes want step 7 = voffset - 4, the lower half's h[-1] = 0
+                const float r_ = buf_load(sh, te < 0 ? v - 4u : v, (unsigned)max(te, 0) * 4u);
+                raw[e] = (te < 0 && half == 0) ? 0.f : r_;
+            }
+        }
+    };
+    auto split8 = [&](const float (&v)[8], bf16x8 (&P)[3]) {
+        unsigned w_[3][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) split3_pair(v[2 * i], v[2 * i + 1], w_[0][i], w_[1][i], w_[2][i]);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) P[p] = __builtin_bit_cast(bf16x8, make_uint4(w_[p][0], w_[p][1], w_[p][2], w_[p][3]));
+    };
+    bf16x8 Af[2][3], Bp[3];
+    auto slot = [&](int chunk, int sl) {            // slot sl = 0..31 of the chunk's work; four slots per unit
+        const int u_ = sl >> 2, k = sl & 3, ks = u_ >> 2, z = (u_ >> 1) & 1, ct = u_ & 1;
+        if (k == 0) {
+            if ((u_ & 3) == 0) {                    // new k-step: the two row tiles' A fragments from the [n'][t] image
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt) {
+                    const float* src = daT + ((chunk & 1) * 256 + 64 * hw + 32 * rt + l31) * PT + 16 * ks + 8 * half;
+                    const float4 a0 = *reinterpret_cast<const float4*>(src), a1 = *reinterpret_cast<const float4*>(src + 4);
+                    const float v[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+                    split8(v, Af[rt]);
+                }
+            }
+            split8(raw, Bp);
+            if (u_ < 7) load_raw(chunk, u_ + 1); else load_raw(max(chunk - 1, 0), 0);
+            return;
+        }
+        // k = 1..3: four of the unit's twelve piece products each (bf16x6 order: small terms first)
+        constexpr int PA[6] = {1, 0, 2, 0, 1, 0}, PB[6] = {1, 2, 0, 1, 0, 0};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = 4 * (k - 1) + i, rt = m / 6, j = m % 6;
+            acc[z][rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Af[rt][PA[j]], Bp[PB[j]], acc[z][rt][ct], 0, 0, 0);
+        }
+    };
+    const int nch = T / CT;
+    load_raw(nch - 1, 0);
+    __syncthreads();                                 // the recurrence's start-up barrier
+    for (int c = nch - 1; c >= 0; --c) {             // the recurrence walks chunk c; chunk c + 1 is complete
+        const bool work = c + 1 < nch;
+#pragma unroll
+        for (int sl = 0; sl < CT; ++sl) {
+            if (work) slot(c + 1, sl);
+            __syncthreads();                         // = the barrier of one recurrence step
+        }
+    }
+#pragma unroll
+    for (int sl = 0; sl < CT; ++sl) slot(0, sl);     // chunk 0, after the recurrence's last step
+#pragma unroll
+    for (int z = 0; z < 2; ++z)
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    out[(64 * hw + 32 * rt + mfma_row(r, half)) * 128 + 64 * z + 32 * ct + l31] = acc[z][rt][ct][r];
+}
+
 // --------------------------------------------------- recurrence bwd with the input gradient inside
 // Same BPTT as lstm_bwd_kernel; in addition dx[b,c,t] = sum_n' w_ih[gate_row(n')][c] da[t][n'] is formed here instead of
 // in a separate GEMM over the 4.2-GB da tensor.  Every lane drops the three bf16 pieces of its da into a wave-private
@@ -1231,6 +1415,27 @@ int wm_lstm_bwd_fused(float* gates, const float* cst, const float* dh_out, const
         wm::dev_mark(done);
     }
     hipLaunchKernelGGL(lstm_bwd_fused_kernel, dim3(B), dim3(256), lds, stream, gates, cst, dh_out, w_hh, w_ih, dx, T);
+    WM_CHECK_LAUNCH();
+    return 0;
+}
+
+// BPTT + the clip's weight gradients in one launch (wave-specialised: see lstm_bwd_ws_kernel), then the fixed-order reduction
+// over clips.  gates: saved activations in, da out (for wm_lstm_dx).  partial: >= B * (256*128 + 256) floats.  T % 32 == 0, T >= 64.
+int wm_lstm_bwd_wgrad(float* gates, const float* cst, const float* dh_out, const float* w_hh, const float* x, const float* h,
+                      float* partial, float* dw_ih, float* dw_hh, float* db_ih, float* db_hh, int B, int T, int accumulate,
+                      hipStream_t stream) {
+    if (B <= 0 || (T & 31) || T < 64) return (int)hipErrorInvalidValue;
+    constexpr size_t lds = (size_t)(2 * 256 * 36 + 2 * 64 * 4) * sizeof(float);
+    static wm::DevOnce done;
+    if (!wm::dev_done(done)) {
+        WM_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_bwd_ws_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        wm::dev_mark(done);
+    }
+    hipLaunchKernelGGL(lstm_bwd_ws_kernel, dim3(B), dim3(512), lds, stream, gates, cst, dh_out, w_hh, x, h, partial, T);
+    WM_CHECK_LAUNCH();
+    constexpr int n = 256 * 128 + 256;
+    hipLaunchKernelGGL(lstm_wgrad_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, (const float*)partial, B,
+                       dw_ih, dw_hh, db_ih, db_hh, accumulate);
     WM_CHECK_LAUNCH();
     return 0;
 }

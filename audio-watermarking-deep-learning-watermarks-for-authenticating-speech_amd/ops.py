@@ -537,6 +537,13 @@ class HeadNFn(torch.autograd.Function):
 # ------------------------------------------------------------------------------------------ LSTM
 _LSTM_FUSED = _os.environ.get("WM_LSTM_FUSED", "1") == "1"     # 0: separate wm_lstm_xproj + wm_lstm_fwd launches
 _LSTM_BWD_FUSED = _os.environ.get("WM_LSTM_BWD_FUSED", "0") == "1"   # 1: wm_lstm_bwd + wm_lstm_dx as one launch
+_LSTM = {"bwd_ws": _os.environ.get("WM_LSTM_BWD_WS", "1") == "1"}
+
+
+def set_lstm_bwd_wave_specialised(on: bool):
+    """LSTM backward: 1 (default) wm_lstm_bwd_wgrad -- the weight gradients are formed by four helper waves beside the recurrence, from
+    the chunk of da it has just finished (T % 32 == 0, T >= 64); 0 wm_lstm_bwd followed by wm_lstm_wgrad.  WM_LSTM_BWD_WS=0/1."""
+    _LSTM["bwd_ws"] = bool(on)
 
 
 class LSTMFn(GradAwareFunction):
@@ -580,6 +587,20 @@ class LSTMFn(GradAwareFunction):
         dev, st = x.device, _stream()
         dx = torch.empty_like(x)
         release_deferred_wgrads()                  # side stream: the queued weight-gradient GEMMs run beside the recurrence
+        if _LSTM["bwd_ws"] and not _LSTM_BWD_FUSED and T % 32 == 0 and T >= 64:
+            part = _f32(B * (256 * 128 + 256), device=dev)
+            if all(g is not None for g in ctx.gdst):           # accumulate into the flat gradient store
+                gwi, gwh, gbi, gbh = ctx.gdst
+                lib.wm_lstm_bwd_wgrad(_p(gates), _p(cst), _p(dh), _p(w_hh), _p(x), _p(h), _p(part), _p(gwi), _p(gwh), _p(gbi), _p(gbh),
+                                      B, T, 1, st)
+                lib.wm_lstm_dx(_p(gates), _p(w_ih), _p(dx), B, T, st)
+                return dx, None, None, None, None
+            dwi, dwh = torch.empty_like(w_ih), torch.empty_like(w_hh)
+            dbi, dbh = _f32(256, device=dev), _f32(256, device=dev)
+            lib.wm_lstm_bwd_wgrad(_p(gates), _p(cst), _p(dh), _p(w_hh), _p(x), _p(h), _p(part), _p(dwi), _p(dwh), _p(dbi), _p(dbh),
+                                  B, T, 0, st)
+            lib.wm_lstm_dx(_p(gates), _p(w_ih), _p(dx), B, T, st)
+            return dx, dwi, dwh, dbi, dbh
         if _LSTM_BWD_FUSED:                        # measured: no faster than the two launches; off by default
             lib.wm_lstm_bwd_fused(_p(gates), _p(cst), _p(dh), _p(w_hh), _p(w_ih), _p(dx), B, T, st)   # gates now holds da
         else:

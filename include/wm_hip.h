@@ -187,6 +187,14 @@ int wm_lstm_bwd_fused(float* gates, const float* cst, const float* dh_out, const
                       int B, int T, wm_stream_t stream);
 int wm_lstm_wgrad(const float* da, const float* x, const float* h, float* partial, float* dw_ih, float* dw_hh,
                   float* db_ih, float* db_hh, int B, int T, int accumulate, wm_stream_t stream);
+/* wm_lstm_bwd + wm_lstm_wgrad in one launch (py/main16.py:141,153 under autograd): four more waves per workgroup form the clip's
+ * dW_ih / dW_hh on the matrix cores (bf16x6) out of the 32-step chunk of da the recurrence has just finished, from an LDS image --
+ * da is not read back from HBM for them; bias gradients from the recurrence lanes.  gates: saved activations in, da out (still
+ * written: wm_lstm_dx reads it).  partial >= B * (256*128 + 256) floats (one slab per clip, reduced in fixed order); accumulate as
+ * wm_lstm_wgrad.  T % 32 == 0 and T >= 64 (hipErrorInvalidValue otherwise: use the two separate entry points). */
+int wm_lstm_bwd_wgrad(float* gates, const float* cst, const float* dh_out, const float* w_hh, const float* x, const float* h,
+                      float* partial, float* dw_ih, float* dw_hh, float* db_ih, float* db_hh, int B, int T, int accumulate,
+                      wm_stream_t stream);
 
 /* ---- nn.Embedding(2**bits,64) lookup :158 and its dense gradient ------------------------------------------- */
 int wm_embed_gather(const float* table, const long long* message, float* vec, int B, int nrows, int* err, wm_stream_t stream);

@@ -563,6 +563,41 @@ def test_lstm_launch_variants(awm, dev, monkeypatch, fwd_fused, bwd_fused, B, T)
     check(bid.grad, bir.grad, GRAD_TOL, "lstm db_ih")
 
 
+@pytest.mark.parametrize("B,T", [(2, 64), (1, 96), (3, 1024)])
+def test_lstm_bwd_wave_specialised(awm, dev, monkeypatch, B, T):
+    """wm_lstm_bwd_wgrad (BPTT with four helper waves forming dW_ih / dW_hh / db out of the LDS image of the chunk of da just finished;
+    T % 32 == 0) against the oracle and against wm_lstm_bwd + wm_lstm_wgrad: the recurrence is the same instruction stream, so dx must be
+    bit-identical; the weight gradients are the same bf16x6 products summed clip by clip instead of tile by tile (fp32 accumulate,
+    fp64 across clips): within 2e-6 of max |dW|."""
+    from awm_amd import ops
+    g = torch.Generator().manual_seed(50)
+    k = 1.0 / 8.0
+    wi, wh = (torch.rand(256, 64, generator=g) * 2 - 1) * k, (torch.rand(256, 64, generator=g) * 2 - 1) * k
+    bi, bh = (torch.rand(256, generator=g) * 2 - 1) * k, (torch.rand(256, generator=g) * 2 - 1) * k
+    x = rnd(B, 64, T, seed=51)
+    gg = rnd(B, 64, T, seed=52)
+    xr, wir, whr, bir, bhr = (t.clone().requires_grad_() for t in (x, wi, wh, bi, bh))
+    O.lstm_forward(xr.permute(0, 2, 1), wir, whr, bir, bhr).permute(0, 2, 1).backward(gg)
+    calls, grads = [], []
+    orig = awm.lib.wm_lstm_bwd_wgrad
+
+    def spy(*a):
+        calls.append(1)
+        return orig(*a)
+    monkeypatch.setattr(awm.lib, "wm_lstm_bwd_wgrad", spy)
+    for ws in (True, False):
+        monkeypatch.setitem(ops._LSTM, "bwd_ws", ws)
+        xd, wid, whd, bid, bhd = (t.to(dev).requires_grad_() for t in (x, wi, wh, bi, bh))
+        ops.LSTMFn.apply(xd, wid, whd, bid, bhd).backward(gg.to(dev))
+        grads.append([t.grad.clone() for t in (xd, wid, whd, bid, bhd)])
+    assert len(calls) == 1, "the wave-specialised launch did not run"
+    for name, a, r in zip(("dx", "dW_ih", "dW_hh", "db_ih", "db_hh"), grads[0], (xr, wir, whr, bir, bhr)):
+        check(a, r.grad, GRAD_TOL, "lstm (wave-specialised) " + name)
+    assert torch.equal(grads[0][0], grads[1][0]), "dx differs from the two-launch path"
+    for name, a, b_ in zip(("dW_ih", "dW_hh", "db_ih", "db_hh"), grads[0][1:], grads[1][1:]):
+        assert rel_err(a, b_) < 2e-6, (name, rel_err(a, b_))
+
+
 def test_lstm_long_horizon(awm, dev):
     """all 16000 dependent steps (SURVEY.md hard part 1): drift must stay inside 1e-4"""
     from awm_amd import ops
