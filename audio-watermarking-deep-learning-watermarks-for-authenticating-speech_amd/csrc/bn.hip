@@ -259,6 +259,40 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __re
     }
 }
 
+
+// max |x| over a tensor -> the power-of-two scale of the f16 two-piece split kernels: {gs, 1 / gs} with max |x| gs in (2^(L-1), 2^L].
+// Pass 1: one partial per workgroup (streaming, 1024 workgroups); pass 2: one workgroup.
+__global__ __launch_bounds__(256) void absmax_kernel(const float4* __restrict__ x, size_t n4, float* __restrict__ partial) {
+    __shared__ float red[4];
+    float m = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const float4 v = stream_load(x + i);
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+__global__ __launch_bounds__(256) void gscale_from_max_kernel(const float* __restrict__ partial, int n, float log2_target,
+                                                              float* __restrict__ gscale) {
+    __shared__ float red[4];
+    float m = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) m = fmaxf(m, partial[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        float gs = 1.f;
+        if (m > 0.f && m < 3.0e38f) gs = exp2f(floorf(log2_target - log2f(m)));      // NaN / inf / all-zero input: scale 1
+        gs = fminf(fmaxf(gs, 1.0e-30f), 1.0e30f);
+        gscale[0] = gs; gscale[1] = 1.f / gs;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -332,6 +366,20 @@ int wm_bn_bwd_finalize(const float* partials, int nparts, double count, const fl
     if (gscale && (!dzmax || nmax <= 0)) return (int)hipErrorInvalidValue;
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(1024), 0, stream, partials, nparts, count, gamma, save_mean,
                        save_invstd, A, Bc, Cc, dgamma, dbeta, accumulate, eval_mode, dzmax, nmax, gscale);
+    WM_CHECK_LAUNCH();
+    return 0;
+}
+
+
+// {gs, 1 / gs} for a gradient tensor that an f16 two-piece split kernel is about to read: gs = the power of two that puts max |x|
+// into (2^(L-1), 2^L], L = log2_target.  scratch: >= 1024 floats.  n % 4 == 0.
+int wm_gscale_absmax(const float* x, long long n, float* scratch, float log2_target, float* gscale, hipStream_t stream) {
+    if (n <= 0 || (n & 3)) return (int)hipErrorInvalidValue;
+    const size_t n4 = (size_t)n / 4;
+    const int grid = (int)((n4 + 255) / 256 < 1024 ? (n4 + 255) / 256 : 1024);
+    hipLaunchKernelGGL(absmax_kernel, dim3(grid), dim3(256), 0, stream, reinterpret_cast<const float4*>(x), n4, scratch);
+    WM_CHECK_LAUNCH();
+    hipLaunchKernelGGL(gscale_from_max_kernel, dim3(1), dim3(256), 0, stream, (const float*)scratch, grid, log2_target, gscale);
     WM_CHECK_LAUNCH();
     return 0;
 }

@@ -1819,10 +1819,12 @@ int launch_conv64bf7(const Conv64Args& a, hipStream_t stream) {
 // a 128-column tile (336 MFMAs per wave), and LDS only carries the input image, double-buffered (2 x 58 KB): the split of
 // tile i+1 and the fetch of tile i+2 ride, one hand-pinned slice per MFMA, in the matrix phase of tile i.  T % 128 == 0.
 // ---------------------------------------------------------------------------------------------
-template <int PRO, int EPI>
+// H = true: f16 two-piece build (three products per product; weight image from wm_pack_w64_h7: w * ws; a.pb, when given, = {gs, 1 / gs}:
+// the input -- a gradient -- is multiplied by gs before the split and clamped to the f16 range; the accumulators leave times 1 / (ws gs))
+template <int PRO, int EPI, bool H = false>
 __global__ __launch_bounds__(256) void conv64bf7p_kernel(Conv64Args a) {
     static_assert(PRO == PRO_NONE || PRO == PRO_ADDVEC, "prologue: none or + vec[b][c]");
-    constexpr int KW = 7, PAD = 3, NT = 128, ROWS = NT + 2 * PAD, PITCH = 72, NP = 3, NC = 4, NS = KW * 4;
+    constexpr int KW = 7, PAD = 3, NT = 128, ROWS = NT + 2 * PAD, PITCH = 72, NP = H ? 2 : 3, NC = 4, NS = KW * 4;
     constexpr int XBUF = NP * ROWS * PITCH;               // bf16 elements per input image
     extern __shared__ __align__(16) unsigned char smem_raw[];
     unsigned short* Xb0 = reinterpret_cast<unsigned short*>(smem_raw);             // 2 x [NP][ROWS][PITCH]
@@ -1834,7 +1836,7 @@ __global__ __launch_bounds__(256) void conv64bf7p_kernel(Conv64Args a) {
     const int tilesPerClip = T / NT, ntiles = a.B * tilesPerClip;
 
     // ---- resident weight fragments: packed image [NP][KW][64 out][64 in] bf16; k-step s = tap * 4 + 16-channel block
-    bf16x8 Wr[NS][NP];
+    u32x4 Wr[NS][NP];
     {
         const uint4* wg = reinterpret_cast<const uint4*>(a.wp);
 #pragma unroll
@@ -1844,8 +1846,14 @@ __global__ __launch_bounds__(256) void conv64bf7p_kernel(Conv64Args a) {
                 const int e = ((p * KW + (s >> 2)) * 64 + 32 * mt + l31) * 64 + 16 * (s & 3) + 8 * half;
                 u32x4 w_ = __builtin_bit_cast(u32x4, wg[e >> 3]);
                 if (s >= 8) asm volatile("" : "+a"(w_));      // 336 fragment registers: all but the first 8 k-steps pinned into AGPRs,
-                Wr[s][p] = __builtin_bit_cast(bf16x8, w_);     // where the MFMA reads them in place (no spill / copy-back traffic)
+                Wr[s][p] = w_;                                 // where the MFMA reads them in place (no spill / copy-back traffic)
             }
+    }
+    float gs = 1.f, dinv = 1.f;                    // H: input scale, output scale
+    if (H) {
+        const float* tail = reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(a.wp) + NP * KW * 4096);
+        dinv = tail[1];
+        if (a.pb) { gs = a.pb[0]; dinv *= a.pb[1]; }
     }
     // ---- staging map (fixed per thread): channel pair cp, time quads q0 + 8 i; halo element k: channel hcn[k], image row hr[k]
     const int cp = wave * 8 + (lane & 7), c0 = 2 * cp, q0 = lane >> 3;
@@ -1891,39 +1899,53 @@ __global__ __launch_bounds__(256) void conv64bf7p_kernel(Conv64Args a) {
         float va = (e == 0) ? fa.x : (e == 1) ? fa.y : (e == 2) ? fa.z : fa.w;
         float vb = (e == 0) ? fb.x : (e == 1) ? fb.y : (e == 2) ? fb.z : fb.w;
         if (PRO == PRO_ADDVEC) { va += pv0; vb += pv1; }
+        if (H) { va = __builtin_amdgcn_fmed3f(va * gs, -6.0e4f, 6.0e4f); vb = __builtin_amdgcn_fmed3f(vb * gs, -6.0e4f, 6.0e4f); }
         sva = va; svb = vb;
         asm volatile("" : "+v"(sva), "+v"(svb));
     };
     auto split_st1 = [&]() {
-        const bf16x2 h_ = {(__bf16)sva, (__bf16)svb};
-        sp0 = __builtin_bit_cast(unsigned, h_);
-        sva -= __uint_as_float(sp0 << 16); svb -= __uint_as_float(sp0 & 0xffff0000u);
+        if (H) {
+            const h16x2 h_ = __builtin_convertvector(f32x2{sva, svb}, h16x2);
+            sp0 = __builtin_bit_cast(unsigned, h_);
+            sva -= (float)h_.x; svb -= (float)h_.y;
+        } else {
+            const bf16x2 h_ = {(__bf16)sva, (__bf16)svb};
+            sp0 = __builtin_bit_cast(unsigned, h_);
+            sva -= __uint_as_float(sp0 << 16); svb -= __uint_as_float(sp0 & 0xffff0000u);
+        }
         asm volatile("" : "+v"(sva), "+v"(svb), "+v"(sp0));
     };
+    auto last_piece = [&]() -> unsigned {
+        if (H) return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{sva, svb}, h16x2));
+        const bf16x2 l_ = {(__bf16)sva, (__bf16)svb};
+        return __builtin_bit_cast(unsigned, l_);
+    };
     auto split_st2 = [&]() {
+        if (H) return;                                   // two pieces: no middle one
         const bf16x2 m_ = {(__bf16)sva, (__bf16)svb};
         sp1 = __builtin_bit_cast(unsigned, m_);
         sva -= __uint_as_float(sp1 << 16); svb -= __uint_as_float(sp1 & 0xffff0000u);
         asm volatile("" : "+v"(sva), "+v"(svb), "+v"(sp1));
     };
     auto split_out = [&](unsigned short* X, int i, int e) {
-        const bf16x2 l_ = {(__bf16)sva, (__bf16)svb};
+        const unsigned sp2 = last_piece();
         unsigned* X32 = reinterpret_cast<unsigned*>(X);
         const int o = (PAD + 4 * (q0 + 8 * i) + e) * (PITCH / 2) + cp;
-        X32[o] = sp0; X32[(ROWS * PITCH >> 1) + o] = sp1; X32[2 * (ROWS * PITCH >> 1) + o] = __builtin_bit_cast(unsigned, l_);
+        X32[o] = sp0; if (!H) X32[(ROWS * PITCH >> 1) + o] = sp1; X32[(NP - 1) * (ROWS * PITCH >> 1) + o] = sp2;
     };
     auto halo_pick = [&](int t0, int k) {
         const int t = t0 - PAD + hr[k];
         float v = hl[k];
         if (PRO == PRO_ADDVEC) v += hv[k];
+        if (H) v = __builtin_amdgcn_fmed3f(v * gs, -6.0e4f, 6.0e4f);
         sva = (t < 0 || t >= T) ? 0.f : v; svb = 0.f;
         asm volatile("" : "+v"(sva), "+v"(svb));
     };
     auto halo_out = [&](unsigned short* X, int k) {
-        const bf16x2 l_ = {(__bf16)sva, (__bf16)svb};
+        const unsigned sp2 = last_piece();
         if (tid + k * 256 < 64 * 2 * PAD) {
             const int o = hr[k] * PITCH + hcn[k];
-            X[o] = (unsigned short)sp0; X[ROWS * PITCH + o] = (unsigned short)sp1; X[2 * ROWS * PITCH + o] = (unsigned short)__builtin_bit_cast(unsigned, l_);
+            X[o] = (unsigned short)sp0; if (!H) X[ROWS * PITCH + o] = (unsigned short)sp1; X[(NP - 1) * ROWS * PITCH + o] = (unsigned short)sp2;
         }
     };
     {   // first tile: split serially, then fetch the second
@@ -1941,6 +1963,10 @@ __global__ __launch_bounds__(256) void conv64bf7p_kernel(Conv64Args a) {
     __syncthreads();
 
     int buf = 0;
+    auto mma = [&](const u32x4& A_, const u32x4& B_, f32x16 c) -> f32x16 {
+        if (H) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, A_), __builtin_bit_cast(h16x8, B_), c, 0, 0, 0);
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A_), __builtin_bit_cast(bf16x8, B_), c, 0, 0, 0);
+    };
 #define FENCE __builtin_amdgcn_sched_barrier(0)
     while (tile < ntiles) {
         // registers: the operands of tile + tstep (clamped: a tile past the end lands in the image nobody reads again)
@@ -1955,9 +1981,9 @@ __global__ __launch_bounds__(256) void conv64bf7p_kernel(Conv64Args a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
         const unsigned short* xrow = xcur + (64 * nh + l31) * PITCH + 8 * half;
-        bf16x8 Bq[2][NP];
+        u32x4 Bq[2][NP];
 #pragma unroll
-        for (int p = 0; p < NP; ++p) Bq[0][p] = *reinterpret_cast<const bf16x8*>(xrow + p * ROWS * PITCH);
+        for (int p = 0; p < NP; ++p) Bq[0][p] = *reinterpret_cast<const u32x4*>(xrow + p * ROWS * PITCH);
         // the embedding values of the tile in the registers become current; load_halo() below refills the "next" set
         pv0 = nv0; pv1 = nv1; hv[0] = nhv[0]; hv[1] = nhv[1];
 #define BF7_SLICE(k)                                                                                                        \
@@ -1983,16 +2009,22 @@ __global__ __launch_bounds__(256) void conv64bf7p_kernel(Conv64Args a) {
                 const int s1_ = (h + 1) >> 1, n1 = (h + 1) & 1;
 #pragma unroll
                 for (int p = 0; p < NP; ++p)
-                    Bq[(h + 1) & 1][p] = *reinterpret_cast<const bf16x8*>(xrow + (p * ROWS + 32 * n1 + (s1_ >> 2)) * PITCH + 16 * (s1_ & 3));
+                    Bq[(h + 1) & 1][p] = *reinterpret_cast<const u32x4*>(xrow + (p * ROWS + 32 * n1 + (s1_ >> 2)) * PITCH + 16 * (s1_ & 3));
             }
-            const bf16x8* Bf = Bq[h & 1];
+            const u32x4* Bf = Bq[h & 1];
             FENCE;
-            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wr[s][1], Bf[1], acc[nt], 0, 0, 0); FENCE; BF7_SLICE(0) FENCE;
-            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wr[s][0], Bf[2], acc[nt], 0, 0, 0); FENCE; BF7_SLICE(1) FENCE;
-            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wr[s][2], Bf[0], acc[nt], 0, 0, 0); FENCE; BF7_SLICE(2) FENCE;
-            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wr[s][0], Bf[1], acc[nt], 0, 0, 0); FENCE; BF7_SLICE(3) FENCE;
-            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wr[s][1], Bf[0], acc[nt], 0, 0, 0); FENCE;
-            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wr[s][0], Bf[0], acc[nt], 0, 0, 0); FENCE;
+            if (H) {                                     // lo hi, hi lo, hi hi
+                acc[nt] = mma(Wr[s][1], Bf[0], acc[nt]); FENCE; BF7_SLICE(0) FENCE; BF7_SLICE(1) FENCE;
+                acc[nt] = mma(Wr[s][0], Bf[1], acc[nt]); FENCE; BF7_SLICE(3) FENCE;
+                acc[nt] = mma(Wr[s][0], Bf[0], acc[nt]); FENCE;
+            } else {
+                acc[nt] = mma(Wr[s][1], Bf[1], acc[nt]); FENCE; BF7_SLICE(0) FENCE;
+                acc[nt] = mma(Wr[s][0], Bf[2], acc[nt]); FENCE; BF7_SLICE(1) FENCE;
+                acc[nt] = mma(Wr[s][2], Bf[0], acc[nt]); FENCE; BF7_SLICE(2) FENCE;
+                acc[nt] = mma(Wr[s][0], Bf[1], acc[nt]); FENCE; BF7_SLICE(3) FENCE;
+                acc[nt] = mma(Wr[s][1], Bf[0], acc[nt]); FENCE;
+                acc[nt] = mma(Wr[s][0], Bf[0], acc[nt]); FENCE;
+            }
         }
 #undef BF7_SLICE
         // epilogue (serial: 32 values against 336 MFMAs)
@@ -2004,6 +2036,7 @@ __global__ __launch_bounds__(256) void conv64bf7p_kernel(Conv64Args a) {
                 for (int r = 0; r < 16; ++r) {
                     const int row = (r & 3) + 8 * (r >> 2);
                     float v = acc[nt][r];
+                    if (H) v *= dinv;
                     if (EPI == EPI_BIAS) v += Cs[32 * mt + 4 * half + row];
                     yb[(size_t)row * T + 32 * nt] = v;
                 }
@@ -2015,11 +2048,11 @@ __global__ __launch_bounds__(256) void conv64bf7p_kernel(Conv64Args a) {
 #undef FENCE
 }
 
-template <int PRO, int EPI>
+template <int PRO, int EPI, bool H = false>
 int launch_conv64bf7p(const Conv64Args& a, hipStream_t stream) {
-    constexpr size_t lds = (size_t)(2 * 3 * 134 * 72) * 2 + 64 * sizeof(float);
+    constexpr size_t lds = (size_t)(2 * (H ? 2 : 3) * 134 * 72) * 2 + 64 * sizeof(float);
     static wm::DevOnce attr_done;
-    auto kern = conv64bf7p_kernel<PRO, EPI>;
+    auto kern = conv64bf7p_kernel<PRO, EPI, H>;
     if (!wm::dev_done(attr_done)) {
         WM_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         wm::dev_mark(attr_done);
@@ -2797,9 +2830,11 @@ int launch_wgrad64bf(const Wgrad64Args& a, int* grid_out, hipStream_t stream) {
 // the seven shifted B fragments from it in registers (dword selects for even shifts, v_alignbit for odd ones), so the
 // matrix phase needs 15 LDS reads per 84 MFMAs.  The two time halves meet in the final slab reduction.
 // ---------------------------------------------------------------------------------------------
-template <int XPRO>
+// H = true: f16 two-piece build (three products per product): a.ga = {gs, 1 / gs}, the gradient is multiplied by gs before the split and
+// clamped to the f16 range, x is split unscaled, the sums leave times 1 / gs (the bias sums are formed from the unscaled gradient)
+template <int XPRO, bool H = false>
 __global__ __launch_bounds__(256) void wgrad64bf7_kernel(Wgrad64Args a) {
-    constexpr int KW = 7, PAD = 3, NT = 128, NP = 3, PG = 136, PX = 152, XO = 8;
+    constexpr int KW = 7, PAD = 3, NT = 128, NP = H ? 2 : 3, PG = 136, PX = 152, XO = 8;
     constexpr int QR = NT / 4, NV = 64 * QR / 256;
     extern __shared__ __align__(16) unsigned char smem_raw[];
     unsigned short* Gb = reinterpret_cast<unsigned short*>(smem_raw);          // [NP][64][PG]
@@ -2815,6 +2850,7 @@ __global__ __launch_bounds__(256) void wgrad64bf7_kernel(Wgrad64Args a) {
     float bsum[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) bsum[i] = 0.f;
+    const float gs = (H && a.ga) ? a.ga[0] : 1.f, ginv = (H && a.ga) ? a.ga[1] : 1.f;
 
     auto halo_of = [&](int k, int t0, int& c, int& e, int& t) {   // k-th halo element of this thread: channel, image element, time
         const int idx = min(tid + k * 256, 64 * 2 * PAD - 1);
@@ -2842,6 +2878,14 @@ __global__ __launch_bounds__(256) void wgrad64bf7_kernel(Wgrad64Args a) {
         }
     };
     auto put4 = [&](unsigned short* dst, int stride_p, float v0, float v1, float v2, float v3) {
+        if (H) {
+            const h16x2 ha = __builtin_convertvector(f32x2{v0, v1}, h16x2), hb = __builtin_convertvector(f32x2{v2, v3}, h16x2);
+            const h16x2 la = __builtin_convertvector(f32x2{v0 - (float)ha.x, v1 - (float)ha.y}, h16x2);
+            const h16x2 lb = __builtin_convertvector(f32x2{v2 - (float)hb.x, v3 - (float)hb.y}, h16x2);
+            *reinterpret_cast<uint2*>(dst) = make_uint2(__builtin_bit_cast(unsigned, ha), __builtin_bit_cast(unsigned, hb));
+            *reinterpret_cast<uint2*>(dst + stride_p) = make_uint2(__builtin_bit_cast(unsigned, la), __builtin_bit_cast(unsigned, lb));
+            return;
+        }
         unsigned a0, a1, a2, b0, b1, b2;
         split3_pair(v0, v1, a0, a1, a2);
         split3_pair(v2, v3, b0, b1, b2);
@@ -2858,6 +2902,10 @@ __global__ __launch_bounds__(256) void wgrad64bf7_kernel(Wgrad64Args a) {
             if (XPRO == PRO_ADDVEC) { u.x += xv[i]; u.y += xv[i]; u.z += xv[i]; u.w += xv[i]; }
             if (t >= T) { v = make_float4(0.f, 0.f, 0.f, 0.f); u = v; }
             bsum[i] += (v.x + v.y) + (v.z + v.w);
+            if (H) {
+                v.x = __builtin_amdgcn_fmed3f(v.x * gs, -6.0e4f, 6.0e4f); v.y = __builtin_amdgcn_fmed3f(v.y * gs, -6.0e4f, 6.0e4f);
+                v.z = __builtin_amdgcn_fmed3f(v.z * gs, -6.0e4f, 6.0e4f); v.w = __builtin_amdgcn_fmed3f(v.w * gs, -6.0e4f, 6.0e4f);
+            }
             put4(Gb + c * PG + 4 * q, 64 * PG, v.x, v.y, v.z, v.w);
             put4(Xb + c * PX + XO + 4 * q, 64 * PX, u.x, u.y, u.z, u.w);
         }
@@ -2869,10 +2917,16 @@ __global__ __launch_bounds__(256) void wgrad64bf7_kernel(Wgrad64Args a) {
                 float v = hx[k];
                 if (XPRO == PRO_ADDVEC) v += hv[k];
                 if (t < 0 || t >= T) v = 0.f;
-                unsigned p0, p1, p2;
-                split3_pair(v, 0.f, p0, p1, p2);
                 const int o = c * PX + e;
-                Xb[o] = (unsigned short)p0; Xb[64 * PX + o] = (unsigned short)p1; Xb[2 * 64 * PX + o] = (unsigned short)p2;
+                if (H) {
+                    const _Float16 h_ = (_Float16)v;
+                    const _Float16 l_ = (_Float16)(v - (float)h_);
+                    Xb[o] = __builtin_bit_cast(unsigned short, h_); Xb[64 * PX + o] = __builtin_bit_cast(unsigned short, l_);
+                } else {
+                    unsigned p0, p1, p2;
+                    split3_pair(v, 0.f, p0, p1, p2);
+                    Xb[o] = (unsigned short)p0; Xb[64 * PX + o] = (unsigned short)p1; Xb[2 * 64 * PX + o] = (unsigned short)p2;
+                }
             }
         }
     };
@@ -2892,17 +2946,21 @@ __global__ __launch_bounds__(256) void wgrad64bf7_kernel(Wgrad64Args a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
 
+    auto mma = [&](const u32x4& A_, const u32x4& B_, f32x16 c) -> f32x16 {
+        if (H) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, A_), __builtin_bit_cast(h16x8, B_), c, 0, 0, 0);
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A_), __builtin_bit_cast(bf16x8, B_), c, 0, 0, 0);
+    };
     while (tile < ntiles) {
         const int next = tile + gridDim.x;
         const int nextc = min(next, ntiles - 1);         // clamped: loaded (valid memory) but never written
 #pragma unroll
         for (int kb = 0; kb < 8; ++kb) {                 // the tile's 128 time steps = 8 k-blocks of 16
             const int e0 = kb * 16 + 8 * half;
-            bf16x8 A[NP];
+            u32x4 A[NP];
             unsigned W[NP][12];
 #pragma unroll
             for (int p = 0; p < NP; ++p) {
-                A[p] = *reinterpret_cast<const bf16x8*>(Gb + (p * 64 + mt * 32 + l31) * PG + e0);
+                A[p] = *reinterpret_cast<const u32x4*>(Gb + (p * 64 + mt * 32 + l31) * PG + e0);
                 const unsigned short* xr = Xb + (p * 64 + nt * 32 + l31) * PX + XO + e0;
                 const uint4 w0 = *reinterpret_cast<const uint4*>(xr - 8), w1 = *reinterpret_cast<const uint4*>(xr),
                             w2 = *reinterpret_cast<const uint4*>(xr + 8);
@@ -2915,7 +2973,7 @@ __global__ __launch_bounds__(256) void wgrad64bf7_kernel(Wgrad64Args a) {
                 // fragment = 8 elements from window element 8 + (tap - PAD): dword d0, odd start -> funnel shift
                 constexpr int dummy = 0; (void)dummy;
                 const int st = 8 + tap - PAD, d0 = st >> 1;
-                bf16x8 Bt[NP];
+                u32x4 Bt[NP];
 #pragma unroll
                 for (int p = 0; p < NP; ++p) {
                     uint4 f;
@@ -2924,9 +2982,14 @@ __global__ __launch_bounds__(256) void wgrad64bf7_kernel(Wgrad64Args a) {
                                        __builtin_amdgcn_alignbit(W[p][d0 + 3], W[p][d0 + 2], 16), __builtin_amdgcn_alignbit(W[p][d0 + 4], W[p][d0 + 3], 16));
                     else
                         f = make_uint4(W[p][d0], W[p][d0 + 1], W[p][d0 + 2], W[p][d0 + 3]);
-                    Bt[p] = __builtin_bit_cast(bf16x8, f);
+                    Bt[p] = u32x4{f.x, f.y, f.z, f.w};
                 }
-                acc[tap] = mfma_bf16x6(A, Bt, acc[tap]);
+                if (H) {                                 // lo hi, hi lo, hi hi
+                    acc[tap] = mma(A[1], Bt[0], acc[tap]); acc[tap] = mma(A[0], Bt[1], acc[tap]); acc[tap] = mma(A[0], Bt[0], acc[tap]);
+                } else {
+                    acc[tap] = mma(A[1], Bt[1], acc[tap]); acc[tap] = mma(A[0], Bt[NP - 1], acc[tap]); acc[tap] = mma(A[NP - 1], Bt[0], acc[tap]);
+                    acc[tap] = mma(A[0], Bt[1], acc[tap]); acc[tap] = mma(A[1], Bt[0], acc[tap]); acc[tap] = mma(A[0], Bt[0], acc[tap]);
+                }
                 if (tap == 0) load_piece(nextc, kb);                 // pieces 0..7 ride along the matrix phase
             }
         }
@@ -2942,7 +3005,7 @@ __global__ __launch_bounds__(256) void wgrad64bf7_kernel(Wgrad64Args a) {
 #pragma unroll
     for (int k = 0; k < KW; ++k)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) out[(k * 64 + mt * 32 + mfma_row(r, half)) * 64 + nt * 32 + l31] = acc[k][r];
+        for (int r = 0; r < 16; ++r) out[(k * 64 + mt * 32 + mfma_row(r, half)) * 64 + nt * 32 + l31] = H ? acc[k][r] * ginv : acc[k][r];
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const float v = half_wave_sum(bsum[i]);
@@ -2950,11 +3013,11 @@ __global__ __launch_bounds__(256) void wgrad64bf7_kernel(Wgrad64Args a) {
     }
 }
 
-template <int XPRO>
+template <int XPRO, bool H = false>
 int launch_wgrad64bf7(const Wgrad64Args& a, int* grid_out, hipStream_t stream) {
-    constexpr size_t lds = (size_t)(3 * 64 * 136 + 3 * 64 * 152) * 2;
+    constexpr size_t lds = (size_t)((H ? 2 : 3) * 64 * 136 + (H ? 2 : 3) * 64 * 152) * 2;
     static wm::DevOnce attr_done;
-    auto kern = wgrad64bf7_kernel<XPRO>;
+    auto kern = wgrad64bf7_kernel<XPRO, H>;
     if (!wm::dev_done(attr_done)) {
         WM_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         wm::dev_mark(attr_done);
@@ -2997,6 +3060,39 @@ __global__ __launch_bounds__(1024) void pack_w64_h_kernel(const float* __restric
         const _Float16 lo = (_Float16)(v - (float)hi);
         wph[i] = __builtin_bit_cast(unsigned short, hi);
         wph[3 * 4096 + i] = __builtin_bit_cast(unsigned short, lo);
+    }
+}
+
+// the same for the 7-tap ConvTranspose1d weight w[in][out][7] (conv64bf7p_kernel<.., H = true>): [2 pieces][7 taps][64 out][64 in] f16 +
+// {ws, 1 / ws}; mode 2 forward, 3 data gradient (as wm_pack_w64_bf7)
+__global__ __launch_bounds__(1024) void pack_w64_h7_kernel(const float* __restrict__ w, unsigned short* __restrict__ wph, int mode) {
+    __shared__ float red[16];
+    __shared__ float sc;
+    float mx = 0.f;
+    for (int i = threadIdx.x; i < 7 * 4096; i += 1024) mx = fmaxf(mx, fabsf(w[i]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float m = 0.f;
+        for (int i = 0; i < 16; ++i) m = fmaxf(m, red[i]);
+        float ws = 1.f;
+        if (m > 0.f && m < 3.0e38f) ws = exp2f(floorf(log2f(1023.f / m)));
+        ws = fminf(fmaxf(ws, 1.0e-30f), 1.0e30f);
+        sc = ws;
+        float* tail = reinterpret_cast<float*>(wph + 2 * 7 * 4096);
+        tail[0] = ws; tail[1] = 1.f / ws;
+    }
+    __syncthreads();
+    const float ws = sc;
+    for (int i = threadIdx.x; i < 7 * 4096; i += 1024) {
+        const int tap = i / 4096, out = (i / 64) % 64, in = i % 64;
+        const float v = ((mode == 2) ? w[(in * 64 + out) * 7 + (6 - tap)] : w[(out * 64 + in) * 7 + tap]) * ws;
+        const _Float16 hi = (_Float16)v;
+        const _Float16 lo = (_Float16)(v - (float)hi);
+        wph[i] = __builtin_bit_cast(unsigned short, hi);
+        wph[7 * 4096 + i] = __builtin_bit_cast(unsigned short, lo);
     }
 }
 
@@ -3870,9 +3966,18 @@ int wm_pack_w64_bf7(const float* w, void* wpb, int mode, hipStream_t stream) {
     return 0;
 }
 int wm_conv64_bf7(const float* x, const void* wpb, const float* vec, const float* bias, float* y, int B, int T, int pro, int epi,
-                  hipStream_t stream) {
+                  int arith, const float* gscale, hipStream_t stream) {
     if (B <= 0 || T <= 0 || (T & 3)) return (int)hipErrorInvalidValue;
-    Conv64Args a{x, nullptr, reinterpret_cast<const float*>(wpb), vec, nullptr, nullptr, bias, nullptr, nullptr, nullptr, y, nullptr, B, T};
+    Conv64Args a{x, nullptr, reinterpret_cast<const float*>(wpb), vec, gscale, nullptr, bias, nullptr, nullptr, nullptr, y, nullptr, B, T};
+    if (arith == 1) {                     // f16 two-piece split (wpb from wm_pack_w64_h7): the pipelined kernel only
+        if (!WM_BF7_PIPE || (T & 127)) return (int)hipErrorInvalidValue;
+        if (pro == PRO_NONE && epi == EPI_BIAS) return launch_conv64bf7p<PRO_NONE, EPI_BIAS, true>(a, stream);
+        if (pro == PRO_ADDVEC && epi == EPI_BIAS) return launch_conv64bf7p<PRO_ADDVEC, EPI_BIAS, true>(a, stream);
+        if (pro == PRO_NONE && epi == EPI_NONE) return launch_conv64bf7p<PRO_NONE, EPI_NONE, true>(a, stream);
+        return (int)hipErrorInvalidValue;
+    }
+    if (arith != 0) return (int)hipErrorInvalidValue;
+    a.pb = nullptr;
 #if WM_BF7_PIPE
     if ((T & 127) == 0) {                 // register-resident weights + double-buffered input image (conv64bf7p_kernel)
         if (pro == PRO_NONE && epi == EPI_BIAS) return launch_conv64bf7p<PRO_NONE, EPI_BIAS>(a, stream);
@@ -3886,13 +3991,23 @@ int wm_conv64_bf7(const float* x, const void* wpb, const float* vec, const float
     return (int)hipErrorInvalidValue;
 }
 
+int wm_pack_w64_h7(const float* w, void* wph, int mode, hipStream_t stream) {
+    if (mode != 2 && mode != 3) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(pack_w64_h7_kernel, dim3(1), dim3(1024), 0, stream, w, reinterpret_cast<unsigned short*>(wph), mode);
+    WM_CHECK_LAUNCH();
+    return 0;
+}
+
 // bf16x6 build of the 7-tap ConvTranspose1d weight gradient (= wm_wgrad64 with KW 7, gpro 0, layout 1): dw [in][out][7]
 int wm_wgrad64_bf7(const float* g, const float* x, const float* vec, float* partial, float* dw, float* dbias, int B, int T,
-                   int xpro, int accumulate, hipStream_t stream) {
-    if (B <= 0 || T <= 0 || (T & 3)) return (int)hipErrorInvalidValue;
-    Wgrad64Args a{g, nullptr, nullptr, nullptr, nullptr, x, vec, nullptr, partial, B, T};
+                   int xpro, int accumulate, int arith, const float* gscale, hipStream_t stream) {
+    if (B <= 0 || T <= 0 || (T & 3) || (arith != 0 && arith != 1) || (arith == 1 && !gscale)) return (int)hipErrorInvalidValue;
+    Wgrad64Args a{g, nullptr, arith == 1 ? gscale : nullptr, nullptr, nullptr, x, vec, nullptr, partial, B, T};
     int grid = 0, rc = (int)hipErrorInvalidValue;
-    if (xpro == PRO_ADDVEC) rc = launch_wgrad64bf7<PRO_ADDVEC>(a, &grid, stream);
+    if (arith == 1) {
+        if (xpro == PRO_ADDVEC) rc = launch_wgrad64bf7<PRO_ADDVEC, true>(a, &grid, stream);
+        else if (xpro == PRO_NONE) rc = launch_wgrad64bf7<PRO_NONE, true>(a, &grid, stream);
+    } else if (xpro == PRO_ADDVEC) rc = launch_wgrad64bf7<PRO_ADDVEC>(a, &grid, stream);
     else if (xpro == PRO_NONE) rc = launch_wgrad64bf7<PRO_NONE>(a, &grid, stream);
     if (rc) return rc;
     const int n = 7 * 4096 + 64;

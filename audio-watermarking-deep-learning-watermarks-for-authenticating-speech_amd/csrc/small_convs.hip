@@ -471,7 +471,10 @@ int wm_stem_fwd(const float* s, const float* w, const float* bias, float* y, int
     return 0;
 }
 
-// partial: >= 256*512 floats of scratch.  ds may be NULL (Generator stem: the clip is data); only clips [0, nds) get a ds row
+#ifndef WM_STEM_WGS_PER_CU
+#define WM_STEM_WGS_PER_CU 2      // 75 KB of LDS per workgroup: two fit a CU, one's matrix phase runs under the other's loads / ds phase
+#endif
+// partial: >= 512*512 floats of scratch.  ds may be NULL (Generator stem: the clip is data); only clips [0, nds) get a ds row
 // (Detector stem: the clean half of [watermarked; clean] needs no input gradient).
 int wm_stem_bwd(const float* g, const float* s, const float* w, float* ds, float* partial, float* dw, float* db, int B,
                 int T, int nds, int accumulate, hipStream_t stream) {
@@ -483,7 +486,7 @@ int wm_stem_bwd(const float* g, const float* s, const float* w, float* ds, float
         wm::dev_mark(attr_done);
     }
     const int ntiles = B * ((T + 255) / 256);
-    const int grid = ntiles < kNumCU ? ntiles : kNumCU;
+    const int grid = ntiles < WM_STEM_WGS_PER_CU * kNumCU ? ntiles : WM_STEM_WGS_PER_CU * kNumCU;
     hipLaunchKernelGGL(stem_bwd_kernel, dim3(grid), dim3(256), lds, stream, g, s, w, ds, partial, B, T, nds);
     WM_CHECK_LAUNCH();
     hipLaunchKernelGGL(stem_reduce_kernel, dim3(2), dim3(256), 0, stream, (const float*)partial, grid, dw, db, accumulate);

@@ -151,7 +151,8 @@ _CONV = {"bf16x6": _os.environ.get("WM_CONV_BF16X6", "1") == "1", "schedule": 2,
          "mask_on_load": _os.environ.get("WM_MASK_ON_LOAD", "1") == "1",
          "pair_fold": _os.environ.get("WM_PAIR_FOLD", "1") == "1",
          "bwd_f16x3": _os.environ.get("WM_BWD_F16X3", "1") == "1",
-         "fwd_f16x3": _os.environ.get("WM_FWD_F16X3", "1") == "1"}
+         "fwd_f16x3": _os.environ.get("WM_FWD_F16X3", "1") == "1",
+         "conv7_f16x3": _os.environ.get("WM_CONV7_F16X3", "1") == "1"}
 
 
 def set_conv_bf_schedule(schedule: int):
@@ -221,6 +222,26 @@ def pack_w64_bf(w: torch.Tensor, mode: int) -> torch.Tensor:
     wpb = torch.empty(3 * 3 * 4096, dtype=torch.int16, device=w.device)
     lib.wm_pack_w64_bf(_p(w), _p(wpb), mode, _stream())
     return wpb
+
+
+def set_conv7_f16x3(on: bool):
+    """ConvTranspose1d(64,64,7) forward / data gradient / weight gradient (T % 128 == 0): 1 (default) the f16 two-piece split (three
+    products per product; weights scaled by a power of two from max |w|, the incoming gradient by one from max |g| -- one streaming
+    pass over g, wm_gscale_absmax), 0 bf16x6.  WM_CONV7_F16X3=0/1 sets the default."""
+    _CONV["conv7_f16x3"] = bool(on)
+
+
+def pack_w64_h7(w: torch.Tensor, mode: int) -> torch.Tensor:
+    wph = torch.empty(2 * 7 * 4096 + 4, dtype=torch.int16, device=w.device)      # two f16 pieces + {ws, 1 / ws}
+    lib.wm_pack_w64_h7(_p(w), _p(wph), mode, _stream())
+    return wph
+
+
+def gscale_absmax(g: torch.Tensor, log2_target: float = 12.0) -> torch.Tensor:
+    """{gs, 1 / gs}: the power of two that puts max |g| into (2^(L-1), 2^L] -- the input scale of the f16 two-piece split kernels"""
+    gsc, scratch = _f32(2, device=g.device), _f32(1024, device=g.device)
+    lib.wm_gscale_absmax(_p(g), g.numel(), _p(scratch), float(log2_target), _p(gsc), _stream())
+    return gsc
 
 
 def pack_w64_bf7(w: torch.Tensor, mode: int) -> torch.Tensor:
@@ -475,7 +496,7 @@ class StemFn(torch.autograd.Function):
         ds = None
         if ctx.needs_input_grad[0]:        # rows >= grad_rows are known not to need a gradient (the clean half): left zero
             ds = torch.empty_like(s) if ctx.grad_rows == B else torch.zeros_like(s)
-        part = _f32(NCU * 512, device=s.device)
+        part = _f32(2 * NCU * 512, device=s.device)
         dw, db = torch.empty_like(w), _f32(64, device=s.device)
         lib.wm_stem_bwd(_p(g), _p(s), _p(w), _p(ds), _p(part), _p(dw), _p(db), B, T, ctx.grad_rows, 0, _stream())
         return ds, dw, db, None
@@ -727,7 +748,10 @@ class ConvT7Fn(torch.autograd.Function):
         y = torch.empty_like(x)
         pro = 2 if vec is not None else 0
         if _CONV["bf16x6"]:
-            lib.wm_conv64_bf7(_p(x), _p(pack_w64_bf7(w, 2)), _p(vec), _p(b), _p(y), B, T, pro, 0, _stream())
+            if _CONV["conv7_f16x3"] and T % 128 == 0:
+                lib.wm_conv64_bf7(_p(x), _p(pack_w64_h7(w, 2)), _p(vec), _p(b), _p(y), B, T, pro, 0, 1, None, _stream())
+            else:
+                lib.wm_conv64_bf7(_p(x), _p(pack_w64_bf7(w, 2)), _p(vec), _p(b), _p(y), B, T, pro, 0, 0, None, _stream())
         else:
             lib.wm_conv64(_p(x), None, _p(pack_w64(w, 7, 2)), _p(vec), None, None, _p(b), None, None, None, _p(y), None, B, T, 7, pro, 0,
                           _stream())
@@ -744,8 +768,12 @@ class ConvT7Fn(torch.autograd.Function):
         B, _, T = x.shape
         dev, st = x.device, _stream()
         dx = torch.empty_like(x)
-        if _CONV["bf16x6"]:
-            lib.wm_conv64_bf7(_p(g), _p(pack_w64_bf7(w, 3)), None, None, _p(dx), B, T, 0, 3, st)
+        h7 = _CONV["bf16x6"] and _CONV["conv7_f16x3"] and T % 128 == 0
+        gsc = gscale_absmax(g) if h7 else None          # one streaming pass over g: the scale both f16-split launches apply to it
+        if h7:
+            lib.wm_conv64_bf7(_p(g), _p(pack_w64_h7(w, 3)), None, None, _p(dx), B, T, 0, 3, 1, _p(gsc), st)
+        elif _CONV["bf16x6"]:
+            lib.wm_conv64_bf7(_p(g), _p(pack_w64_bf7(w, 3)), None, None, _p(dx), B, T, 0, 3, 0, None, st)
         else:
             lib.wm_conv64(_p(g), None, _p(pack_w64(w, 7, 3)), None, None, None, None, None, None, None, _p(dx), None, B, T, 7, 0, 3, st)
         gw, gbias = ctx.gdst
@@ -755,13 +783,13 @@ class ConvT7Fn(torch.autograd.Function):
             part = _f32(2 * NCU * (7 * 4096 + 64), device=dev)
             if _CONV["bf16x6"]:
                 lib.wm_wgrad64_bf7(_p(g), _p(x), _p(vec), _p(part), _p(gw if side else dw), _p(gbias if side else db), B, T,
-                                   2 if vec is not None else 0, 1 if side else 0, _stream())
+                                   2 if vec is not None else 0, 1 if side else 0, 1 if h7 else 0, _p(gsc), _stream())
                 return
             lib.wm_wgrad64(_p(g), None, None, None, None, _p(x), _p(vec), None, _p(part), _p(gw if side else dw),
                            _p(gbias if side else db), B, T, 7, 0, 2 if vec is not None else 0, 1, 1 if side else 0, _stream())
         dw, db = (None, None) if side else (torch.empty_like(w), _f32(64, device=dev))
         if side:
-            _on_side((g, x, vec), wg)
+            _on_side((g, x, vec, gsc), wg)
         else:
             wg()
         dvec = None

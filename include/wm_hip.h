@@ -109,12 +109,20 @@ int wm_pack_w64_h(const float* w, void* wph, int mode, wm_stream_t stream);     
  * wm_pack_w64_bf7 (mode 2 forward | 3 data gradient).  pro 0 x | 2 x + vec[b*64+c]; epi 0 + bias[c] | 3 none. */
 int wm_pack_w64_bf7(const float* w, void* wpb, int mode, wm_stream_t stream);
 int wm_conv64_bf7(const float* x, const void* wpb, const float* vec, const float* bias, float* y, int B, int T, int pro, int epi,
-                  wm_stream_t stream);
+                  int arith, const float* gscale, wm_stream_t stream);
+/* arith 0: bf16x6, wpb from wm_pack_w64_bf7.  arith 1 (T % 128 == 0): f16 two-piece split, three products per product, wpb
+ * [2][7][64][64] f16 + {ws, 1 / ws} from wm_pack_w64_h7 (same modes); gscale (optional; the data-gradient launch passes it) = {gs, 1 / gs}
+ * from wm_gscale_absmax: the input is multiplied by gs before the split and clamped to +-6e4, the result leaves times 1 / (ws gs). */
+int wm_pack_w64_h7(const float* w, void* wph, int mode, wm_stream_t stream);     /* 2 * 7 * 4096 f16 + 2 floats */
+/* {gs, 1 / gs} for a gradient tensor x [n] (n % 4 == 0): gs = the power of two that puts max |x| into (2^(L-1), 2^L], L = log2_target
+ * (12 leaves 2^4 of headroom below the f16 maximum); all-zero / non-finite input gives gs = 1.  scratch >= 1024 floats. */
+int wm_gscale_absmax(const float* x, long long n, float* scratch, float log2_target, float* gscale, wm_stream_t stream);
 
 /* weight gradient of that ConvTranspose1d (= wm_wgrad64 with KW 7, gpro 0, layout 1): dw [in][out][7], dbias [64];
  * xpro 0 | 2 (x + vec[b*64+c]); partial: >= 256 * (7*4096 + 64) floats. */
 int wm_wgrad64_bf7(const float* g, const float* x, const float* vec, float* partial, float* dw, float* dbias, int B, int T,
-                   int xpro, int accumulate, wm_stream_t stream);
+                   int xpro, int accumulate, int arith, const float* gscale, wm_stream_t stream);
+/* arith 1: f16 two-piece split; gscale = wm_gscale_absmax's {gs, 1 / gs} for g (required), x is split unscaled, dbias from the unscaled g */
 
 /* bf16x6 build of the k3 Conv1d weight gradient (contract of wm_wgrad64 with KW = 3, layout 0; gpro / xpro (3,1), (3,0), (0,0)).  accumulate: bit 0 = add to
  * dw / dbias, bit 1 = the output-split build (a wave keeps one 32x32 block per tap: ~200 registers per lane, so the workgroup
@@ -158,7 +166,7 @@ int wm_bn_bwd_finalize(const float* partials, int nparts, double count, const fl
 /* ---- stem / heads: Conv1d(1,64,7,p=3) :134,:177 ; Conv1d(64,1,1) :146 ; Conv1d(64,1+bits,1) :180 (+permute :186) */
 int wm_stem_fwd(const float* s, const float* w, const float* bias, float* y, int B, int T, wm_stream_t stream);
 int wm_stem_bwd(const float* g, const float* s, const float* w, float* ds, float* partial, float* dw, float* db, int B,
-                int T, int nds, int accumulate, wm_stream_t stream);   /* ds rows only for clips [0, nds) */
+                int T, int nds, int accumulate, wm_stream_t stream);   /* ds rows only for clips [0, nds); partial >= 512*512 floats */
 int wm_head1_fwd(const float* x, const float* w, const float* bias, float* y, int B, int T, wm_stream_t stream);
 int wm_head1_bwd(const float* g, const float* x, const float* w, float* dx, float* partial, float* dw, float* db, int B,
                  int T, int accumulate, wm_stream_t stream);

@@ -58,15 +58,20 @@ if not only or "acc" in only:
     print(f"acc vs fp64 (max abs / max|ref|): native fp32 MFMA {float((y1_.double().cpu()-ref).abs().max())/sc:.2e}   bf16x6 {float((y2_.double().cpu()-ref).abs().max())/sc:.2e}   torch CPU fp32 {float((cpu32.double()-ref).abs().max())/sc:.2e}")
 timeit("conv64 k7 fwd addvec/bias", lambda: lib.wm_conv64(_p(x), None, _p(wp7), _p(vec), None, None, _p(bias), None, None, None, _p(y), None, B, T, 7, 2, 0, st), F7, 2 * FR)
 wpb7 = ops.pack_w64_bf7(w7, 2)
-timeit("conv64bf7 k7 fwd addvec/bias", lambda: lib.wm_conv64_bf7(_p(x), _p(wpb7), _p(vec), _p(bias), _p(y), B, T, 2, 0, st), F7, 2 * FR)
-timeit("conv64bf7 k7 dgrad none/none", lambda: lib.wm_conv64_bf7(_p(x), _p(wpb7), None, None, _p(y), B, T, 0, 3, st), F7, 2 * FR)
+timeit("conv64bf7 k7 fwd addvec/bias", lambda: lib.wm_conv64_bf7(_p(x), _p(wpb7), _p(vec), _p(bias), _p(y), B, T, 2, 0, 0, None, st), F7, 2 * FR)
+timeit("conv64bf7 k7 dgrad none/none", lambda: lib.wm_conv64_bf7(_p(x), _p(wpb7), None, None, _p(y), B, T, 0, 3, 0, None, st), F7, 2 * FR)
 timeit("conv64 k7 dgrad none/none", lambda: lib.wm_conv64(_p(x), None, _p(wp7), None, None, None, None, None, None, None, _p(y), None, B, T, 7, 0, 3, st), F7, 2 * FR)
 timeit("wgrad64 k3 bnbwd x bnrelu", lambda: lib.wm_wgrad64(_p(x), _p(x2), _p(c[0]), _p(c[1]), _p(c[2]), _p(x3), _p(c[3]), _p(c[4]), _p(wpart), _p(dw3), _p(db), B, T, 3, 3, 1, 0, 0, st), F3, 3 * FR)
 timeit("wgrad64 k3 bnbwd x none", lambda: lib.wm_wgrad64(_p(x), _p(x2), _p(c[0]), _p(c[1]), _p(c[2]), _p(x3), None, None, _p(wpart), _p(dw3), _p(db), B, T, 3, 3, 0, 0, 0, st), F3, 3 * FR)
 timeit("wgrad64bf k3 bnbwd x bnrelu", lambda: lib.wm_wgrad64_bf(_p(x), _p(x2), _p(c[0]), _p(c[1]), _p(c[2]), _p(x3), _p(c[3]), _p(c[4]), _p(wpart), _p(dw3), _p(db), B, T, 3, 1, 0, st), F3, 3 * FR)
 timeit("wgrad64bf k3 bnbwd x none", lambda: lib.wm_wgrad64_bf(_p(x), _p(x2), _p(c[0]), _p(c[1]), _p(c[2]), _p(x3), None, None, _p(wpart), _p(dw3), _p(db), B, T, 3, 0, 0, st), F3, 3 * FR)
 timeit("wgrad64 k7 none x addvec", lambda: lib.wm_wgrad64(_p(x), None, None, None, None, _p(x3), _p(vec), None, _p(wpart), _p(dw7), _p(db), B, T, 7, 0, 2, 1, 0, st), F7, 2 * FR)
-timeit("wgrad64bf7 k7 none x addvec", lambda: lib.wm_wgrad64_bf7(_p(x), _p(x2), _p(vec), _p(wpart), _p(dw7), _p(db), B, T, 2, 0, st), F7, 2 * FR)
+wph7 = ops.pack_w64_h7(w7, 2); gsc7 = ops.gscale_absmax(x)
+timeit("conv64bf7 k7 fwd addvec/bias  f16x3", lambda: lib.wm_conv64_bf7(_p(x), _p(wph7), _p(vec), _p(bias), _p(y), B, T, 2, 0, 1, None, st), F7, 2 * FR)
+timeit("conv64bf7 k7 dgrad none/none  f16x3", lambda: lib.wm_conv64_bf7(_p(x), _p(wph7), None, None, _p(y), B, T, 0, 3, 1, _p(gsc7), st), F7, 2 * FR)
+timeit("gscale_absmax", lambda: ops.gscale_absmax(x), None, FR)
+timeit("wgrad64bf7 k7 none x addvec  f16x3", lambda: lib.wm_wgrad64_bf7(_p(x), _p(x2), _p(vec), _p(wpart), _p(dw7), _p(db), B, T, 2, 0, 1, _p(gsc7), st), F7, 2 * FR)
+timeit("wgrad64bf7 k7 none x addvec", lambda: lib.wm_wgrad64_bf7(_p(x), _p(x2), _p(vec), _p(wpart), _p(dw7), _p(db), B, T, 2, 0, 0, None, st), F7, 2 * FR)
 timeit("bn_add_relu", lambda: lib.wm_bn_add_relu(_p(x), _p(x2), _p(c[0]), _p(c[1]), _p(y), B, T, st), None, 3 * FR)
 part = _f32(B * 128, device=dev)
 timeit("relu_bwd_reduce", lambda: lib.wm_relu_bwd_reduce(_p(x), _p(x2), _p(x3), _p(y), _p(part), B, T, st), None, 4 * FR)
@@ -95,8 +100,10 @@ timeit("lstm_wgrad", lambda: lib.wm_lstm_wgrad(_p(xp), _p(x), _p(h), _p(lpart), 
 # heads / stem (Detector-side: 2B clips)
 s = torch.randn(2 * B, 1, T, device=dev); ws = torch.randn(64, 1, 7, device=dev); X2 = torch.randn(2 * B, 64, T, device=dev); Y2 = torch.empty_like(X2)
 timeit("stem_fwd (2B)", lambda: lib.wm_stem_fwd(_p(s), _p(ws), _p(bias), _p(Y2), 2 * B, T, st), None, 2 * FR)
-sp = _f32(256 * 512, device=dev); dws = torch.empty_like(ws); ds = torch.empty_like(s)
+sp = _f32(512 * 512, device=dev); dws = torch.empty_like(ws); ds = torch.empty_like(s)
 timeit("stem_bwd +ds (2B)", lambda: lib.wm_stem_bwd(_p(X2), _p(s), _p(ws), _p(ds), _p(sp), _p(dws), _p(db), 2 * B, T, 2 * B, 0, st), None, 2 * FR)
+timeit("stem_bwd, ds for the first half (2B: Detector)", lambda: lib.wm_stem_bwd(_p(X2), _p(s), _p(ws), _p(ds), _p(sp), _p(dws), _p(db), 2 * B, T, B, 0, st), None, 2 * FR)
+timeit("stem_bwd, no ds (B: Generator)", lambda: lib.wm_stem_bwd(_p(X2), _p(s), _p(ws), None, _p(sp), _p(dws), _p(db), B, T, 0, 0, st), None, FR)
 w17 = torch.randn(17, 64, 1, device=dev); b17 = torch.randn(17, device=dev); lg = _f32(2 * B, T, 17, device=dev)
 timeit("headN_fwd (2B)", lambda: lib.wm_headN_fwd(_p(X2), _p(w17), _p(b17), _p(lg), 2 * B, T, 17, st), None, 2 * FR * 1.27)
 hp = _f32(256 * (17 * 64 + 17), device=dev); dw17 = torch.empty_like(w17); db17 = _f32(17, device=dev)

@@ -510,6 +510,42 @@ def test_convT_embed(awm, dev, with_msg, T):
         check(td.grad, tr.grad, FWD_TOL, "embedding grad")
 
 
+@pytest.mark.parametrize("gscale", [1e-9, 1e-4, 1.0, 3e4])
+def test_convT_f16_split_is_fp32_grade(awm, dev, gscale):
+    """ConvTranspose1d(64,64,7) on the f16 two-piece split (forward; data gradient and weight gradient with the incoming gradient scaled
+    by a power of two from max |g| -- wm_gscale_absmax) against fp64, beside the bf16x6 build on the same inputs, for upstream gradient
+    magnitudes 1e-9 ... 3e4 (f16 alone spans 6e-8 ... 6.5e4).  Tolerance: error relative to the result's max below 1e-6 and within
+    3x of bf16x6's + 2e-7."""
+    from awm_amd import ops
+    B, T = 2, 1280
+    x, w, b = rnd(B, 64, T, seed=60), rnd(64, 64, 7, seed=61, scale=0.05), rnd(64, seed=62, scale=0.1)
+    vec = rnd(B, 64, seed=63)
+    g = rnd(B, 64, T, seed=64) * gscale
+    g[0, 3, 100] = 40.0 * gscale                                   # an outlier sets the scale: the bulk sits 2^-5 below it
+    xr, wr, br = (t.double().requires_grad_() for t in (x, w, b))
+    yr = F.conv_transpose1d(xr + vec.double().unsqueeze(-1), wr, br, padding=3)
+    yr.backward(g.double())
+    res = []
+    for h in (False, True):
+        ops.set_conv7_f16x3(h)
+        try:
+            xd, wd, bd = (t.to(dev).requires_grad_() for t in (x, w, b))
+            y = ops.ConvT7Fn.apply(xd, vec.to(dev), wd, bd)
+            y.backward(g.to(dev))
+            res.append((y.detach(), xd.grad, wd.grad, bd.grad))
+        finally:
+            ops.set_conv7_f16x3(True)
+    for name, a, h_, r in zip(("y", "dx", "dw", "db"), res[0], res[1], (yr, xr.grad, wr.grad, br.grad)):
+        e_b, e_h = rel_err(a, r), rel_err(h_, r)
+        print(f"g x {gscale:g} {name}: bf16x6 {e_b:.2e} f16 {e_h:.2e}")
+        assert e_h < 1e-6 and e_h < 3 * e_b + 2e-7, (name, gscale, e_b, e_h)
+    # the scale itself: a power of two that brings max |g| into (2^11, 2^12]; 1 for an all-zero tensor
+    gs = ops.gscale_absmax(g.to(dev)).cpu()
+    m = float(g.abs().max()) * float(gs[0])
+    assert 2048.0 < m <= 4096.0 and float(gs[0]) * float(gs[1]) == 1.0 and float(torch.log2(gs[0])) % 1.0 == 0.0
+    assert ops.gscale_absmax(torch.zeros(1024, device=dev)).cpu().tolist() == [1.0, 1.0]
+
+
 # ------------------------------------------------------------------------------------------ LSTM
 @pytest.mark.parametrize("B,T", [(2, 48), (1, 100), (3, 1000)])
 def test_lstm_small(awm, dev, B, T):
