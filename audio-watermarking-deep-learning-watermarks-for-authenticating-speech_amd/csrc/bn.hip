@@ -371,6 +371,14 @@ int wm_bn_bwd_finalize(const float* partials, int nparts, double count, const fl
 }
 
 
+// the second half alone: maxes [n] = max |x| per producer workgroup (wm_dwgrad64_bf's dzmax output)
+int wm_gscale_from_max(const float* maxes, int n, float log2_target, float* gscale, hipStream_t stream) {
+    if (n <= 0) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(gscale_from_max_kernel, dim3(1), dim3(256), 0, stream, maxes, n, log2_target, gscale);
+    WM_CHECK_LAUNCH();
+    return 0;
+}
+
 // {gs, 1 / gs} for a gradient tensor that an f16 two-piece split kernel is about to read: gs = the power of two that puts max |x|
 // into (2^(L-1), 2^L], L = log2_target.  scratch: >= 1024 floats.  n % 4 == 0.
 int wm_gscale_absmax(const float* x, long long n, float* scratch, float log2_target, float* gscale, hipStream_t stream) {

@@ -3034,30 +3034,34 @@ int launch_wgrad64bf7(const Wgrad64Args& a, int* grid_out, hipStream_t stream) {
 // of two that brings max |w| to [2^9, 2^10), followed by {ws, 1 / ws} as two floats.  One workgroup (12 288 values).
 __global__ __launch_bounds__(1024) void pack_w64_h_kernel(const float* __restrict__ w, unsigned short* __restrict__ wph, int mode) {
     __shared__ float red[16];
-    __shared__ float sc;
+    float v[12];                                    // the thread's 12 of the 12 288 values: one trip to memory
     float mx = 0.f;
-    for (int i = threadIdx.x; i < 3 * 4096; i += 1024) mx = fmaxf(mx, fabsf(w[i]));
+#pragma unroll
+    for (int j = 0; j < 12; ++j) {
+        const int i = threadIdx.x + 1024 * j, tap = i / 4096, out = (i / 64) % 64, in = i % 64;
+        v[j] = (mode == 0) ? w[(out * 64 + in) * 3 + tap] : w[(in * 64 + out) * 3 + (2 - tap)];
+        mx = fmaxf(mx, fabsf(v[j]));
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
     __syncthreads();
+    float m = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) m = fmaxf(m, red[i]);
+    float ws = 1.f;
+    if (m > 0.f && m < 3.0e38f) ws = exp2f(floorf(log2f(1023.f / m)));
+    ws = fminf(fmaxf(ws, 1.0e-30f), 1.0e30f);
     if (threadIdx.x == 0) {
-        float m = 0.f;
-        for (int i = 0; i < 16; ++i) m = fmaxf(m, red[i]);
-        float ws = 1.f;
-        if (m > 0.f && m < 3.0e38f) ws = exp2f(floorf(log2f(1023.f / m)));
-        ws = fminf(fmaxf(ws, 1.0e-30f), 1.0e30f);
-        sc = ws;
         float* tail = reinterpret_cast<float*>(wph + 2 * 3 * 4096);
         tail[0] = ws; tail[1] = 1.f / ws;
     }
-    __syncthreads();
-    const float ws = sc;
-    for (int i = threadIdx.x; i < 3 * 4096; i += 1024) {
-        const int tap = i / 4096, out = (i / 64) % 64, in = i % 64;
-        const float v = ((mode == 0) ? w[(out * 64 + in) * 3 + tap] : w[(in * 64 + out) * 3 + (2 - tap)]) * ws;
-        const _Float16 hi = (_Float16)v;
-        const _Float16 lo = (_Float16)(v - (float)hi);
+#pragma unroll
+    for (int j = 0; j < 12; ++j) {
+        const int i = threadIdx.x + 1024 * j;
+        const float x = v[j] * ws;
+        const _Float16 hi = (_Float16)x;
+        const _Float16 lo = (_Float16)(x - (float)hi);
         wph[i] = __builtin_bit_cast(unsigned short, hi);
         wph[3 * 4096 + i] = __builtin_bit_cast(unsigned short, lo);
     }
@@ -3067,30 +3071,34 @@ __global__ __launch_bounds__(1024) void pack_w64_h_kernel(const float* __restric
 // {ws, 1 / ws}; mode 2 forward, 3 data gradient (as wm_pack_w64_bf7)
 __global__ __launch_bounds__(1024) void pack_w64_h7_kernel(const float* __restrict__ w, unsigned short* __restrict__ wph, int mode) {
     __shared__ float red[16];
-    __shared__ float sc;
+    float v[28];
     float mx = 0.f;
-    for (int i = threadIdx.x; i < 7 * 4096; i += 1024) mx = fmaxf(mx, fabsf(w[i]));
+#pragma unroll
+    for (int j = 0; j < 28; ++j) {
+        const int i = threadIdx.x + 1024 * j, tap = i / 4096, out = (i / 64) % 64, in = i % 64;
+        v[j] = (mode == 2) ? w[(in * 64 + out) * 7 + (6 - tap)] : w[(out * 64 + in) * 7 + tap];
+        mx = fmaxf(mx, fabsf(v[j]));
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
     __syncthreads();
+    float m = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) m = fmaxf(m, red[i]);
+    float ws = 1.f;
+    if (m > 0.f && m < 3.0e38f) ws = exp2f(floorf(log2f(1023.f / m)));
+    ws = fminf(fmaxf(ws, 1.0e-30f), 1.0e30f);
     if (threadIdx.x == 0) {
-        float m = 0.f;
-        for (int i = 0; i < 16; ++i) m = fmaxf(m, red[i]);
-        float ws = 1.f;
-        if (m > 0.f && m < 3.0e38f) ws = exp2f(floorf(log2f(1023.f / m)));
-        ws = fminf(fmaxf(ws, 1.0e-30f), 1.0e30f);
-        sc = ws;
         float* tail = reinterpret_cast<float*>(wph + 2 * 7 * 4096);
         tail[0] = ws; tail[1] = 1.f / ws;
     }
-    __syncthreads();
-    const float ws = sc;
-    for (int i = threadIdx.x; i < 7 * 4096; i += 1024) {
-        const int tap = i / 4096, out = (i / 64) % 64, in = i % 64;
-        const float v = ((mode == 2) ? w[(in * 64 + out) * 7 + (6 - tap)] : w[(out * 64 + in) * 7 + tap]) * ws;
-        const _Float16 hi = (_Float16)v;
-        const _Float16 lo = (_Float16)(v - (float)hi);
+#pragma unroll
+    for (int j = 0; j < 28; ++j) {
+        const int i = threadIdx.x + 1024 * j;
+        const float x = v[j] * ws;
+        const _Float16 hi = (_Float16)x;
+        const _Float16 lo = (_Float16)(x - (float)hi);
         wph[i] = __builtin_bit_cast(unsigned short, hi);
         wph[7 * 4096 + i] = __builtin_bit_cast(unsigned short, lo);
     }
@@ -3129,7 +3137,7 @@ struct DWArgs {
                                                         // one: y = (data gradient + e1) masked, stats = (sum y, sum y py2)
     const float* gscale;                                // H (f16 two-piece split): {gs, 1 / gs}, the power-of-two scale of the rebuilt
                                                         // gradient (wm_bn_bwd_finalize); the weight image carries its own scale
-    float* dzmax;                                       // H, STATS forms: max |y| per workgroup [grid] (sizes the NEXT launch's scale)
+    float* dzmax;                                       // H, epi 1 / 2 / 8: max |y| per workgroup [grid] (sizes the NEXT launch's scale)
 };
 
 // H = false: bf16 three-piece split, six piece products per product (bf16x6).  H = true: f16 TWO-piece split (hi = RNE_f16(x s),
@@ -3698,7 +3706,7 @@ __global__ __launch_bounds__(256) void dwgrad64bf_kernel(DWArgs a) {
                     asm volatile("" : "+v"(s1), "+v"(s2));
                 }
                 dacc[r0] = v0; dacc[r1] = v1;
-                if (H && STATS) vmax = fmaxf(vmax, fmaxf(fabsf(v0), fabsf(v1)));
+                if (H && (STATS || EPI == EPI_ADD)) vmax = fmaxf(vmax, fmaxf(fabsf(v0), fabsf(v1)));   // one v_max3 per pair
                 if (i & 1) {
                     const int q4 = i >> 1;
                     const f32x4 quad = {dacc[4 * q4], dacc[4 * q4 + 1], dacc[4 * q4 + 2], dacc[4 * q4 + 3]};
@@ -3812,14 +3820,15 @@ __global__ __launch_bounds__(256) void dwgrad64bf_kernel(DWArgs a) {
         }
         __syncthreads();
         if (tid < 128) a.stats[(size_t)blockIdx.x * 128 + tid] = red[tid] + red[128 + tid];
-        if (H && a.dzmax) {                                   // max |y| of this workgroup's output: the next launch's gradient scale
+    }
+    if (H && (STATS || EPI == EPI_ADD) && a.dzmax) {          // max |y| of this workgroup's output: the next consumer's gradient scale
+        float* red = reinterpret_cast<float*>(smem_raw);
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
-            __syncthreads();
-            if (lane == 0) red[wave] = vmax;
-            __syncthreads();
-            if (tid == 0) a.dzmax[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-        }
+        for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
+        __syncthreads();
+        if (lane == 0) red[wave] = vmax;
+        __syncthreads();
+        if (tid == 0) a.dzmax[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
     }
 }
 

@@ -237,6 +237,28 @@ def pack_w64_h7(w: torch.Tensor, mode: int) -> torch.Tensor:
     return wph
 
 
+# max |g| per producer workgroup of gradient tensors whose producer formed it anyway, keyed by the tensor OBJECT (a weak reference
+# guards against a recycled id): a hit saves the consumer's streaming pass over g, a miss is merely slower
+_GMAX = {}
+
+
+def _note_gmax(t: torch.Tensor, maxes: torch.Tensor):
+    import weakref
+    if len(_GMAX) > 64:
+        _GMAX.clear()
+    _GMAX[id(t)] = (weakref.ref(t), maxes)
+
+
+def gscale_of(g: torch.Tensor, log2_target: float = 12.0) -> torch.Tensor:
+    """{gs, 1 / gs} for gradient g: from its producer's per-workgroup maxima when it left them (no pass over g), else wm_gscale_absmax"""
+    e = _GMAX.pop(id(g), None)
+    if e is not None and e[0]() is g:
+        gsc = _f32(2, device=g.device)
+        lib.wm_gscale_from_max(_p(e[1]), e[1].numel(), float(log2_target), _p(gsc), _stream())
+        return gsc
+    return gscale_absmax(g, log2_target)
+
+
 def gscale_absmax(g: torch.Tensor, log2_target: float = 12.0) -> torch.Tensor:
     """{gs, 1 / gs}: the power of two that puts max |g| into (2^(L-1), 2^L] -- the input scale of the f16 two-piece split kernels"""
     gsc, scratch = _f32(2, device=g.device), _f32(1024, device=g.device)
@@ -441,8 +463,11 @@ def _resblock_bwd_fused(saved, training, g_out, pre=None, fold=None):
                            _p(gsrc), _p(py2), _p(pmask), _p(dx), _p(fpart), _p(wpart), _p(dw1), _p(db1), B, T, 0, 8, 0, _p(gm), h, _p(gs1), _p(fmax), st)
         fout = (fpart, fmax)
     else:
+        xmax = _f32(NCU, device=dev) if h else None          # max |dx| per workgroup: a consumer that splits dx into f16 pieces
         lib.wm_dwgrad64_bf(_p(dz1), _p(y1), _p(k1[0]), _p(k1[1]), _p(k1[3]), _p(pack(w1, 1)), _p(x), None, None,
-                           _p(gsrc), None, None, _p(dx), None, _p(wpart), _p(dw1), _p(db1), B, T, 0, 2, 0, _p(gm), h, _p(gs1), None, st)
+                           _p(gsrc), None, None, _p(dx), None, _p(wpart), _p(dw1), _p(db1), B, T, 0, 2, 0, _p(gm), h, _p(gs1), _p(xmax), st)
+        if h:
+            _note_gmax(dx, xmax)                             # (ConvT7Fn.backward) then needs no pass over it for its scale
     return dx, (dw1, db1, dg1, dbe1, dw2, db2, dg2, dbe2), fout
 
 
@@ -769,7 +794,7 @@ class ConvT7Fn(torch.autograd.Function):
         dev, st = x.device, _stream()
         dx = torch.empty_like(x)
         h7 = _CONV["bf16x6"] and _CONV["conv7_f16x3"] and T % 128 == 0
-        gsc = gscale_absmax(g) if h7 else None          # one streaming pass over g: the scale both f16-split launches apply to it
+        gsc = gscale_of(g) if h7 else None              # the scale both f16-split launches apply to g (.contiguous() above returns g itself)
         if h7:
             lib.wm_conv64_bf7(_p(g), _p(pack_w64_h7(w, 3)), None, None, _p(dx), B, T, 0, 3, 1, _p(gsc), st)
         elif _CONV["bf16x6"]:

@@ -102,7 +102,7 @@ int wm_dwgrad64_bf(const float* g, const float* g2, const float* ga, const float
  * arith 1: f16 TWO-piece split (22 bits per operand), three products on v_mfma_f32_32x32x16_f16 -- half the matrix work of arith 0,
  *          wpb from wm_pack_w64_h (weights scaled by a
  *          power of two chosen from max |w|, stored behind the image); gscale = wm_bn_bwd_finalize's {gs, 1 / gs} for THIS launch's
- *          g; dzmax (optional, epi 1 / 8): 256 floats, max |y| per workgroup = the dzmax input of the next launch's finalize. */
+ *          g; dzmax (optional, epi 1 / 2 / 8): 256 floats, max |y| per workgroup = the dzmax input of the next launch's finalize. */
 int wm_pack_w64_h(const float* w, void* wph, int mode, wm_stream_t stream);      /* 2 * 3 * 4096 f16 + 2 floats */
 
 /* bf16x6 build of the 7-tap ConvTranspose1d(64,64,7,padding=3) (py/main16.py:144): wpb [3][7][64][64] uint16 from
@@ -117,6 +117,8 @@ int wm_pack_w64_h7(const float* w, void* wph, int mode, wm_stream_t stream);    
 /* {gs, 1 / gs} for a gradient tensor x [n] (n % 4 == 0): gs = the power of two that puts max |x| into (2^(L-1), 2^L], L = log2_target
  * (12 leaves 2^4 of headroom below the f16 maximum); all-zero / non-finite input gives gs = 1.  scratch >= 1024 floats. */
 int wm_gscale_absmax(const float* x, long long n, float* scratch, float log2_target, float* gscale, wm_stream_t stream);
+/* the same from per-workgroup maxima a producer already wrote (wm_dwgrad64_bf's dzmax, epi 1 / 2 / 8): no pass over the tensor */
+int wm_gscale_from_max(const float* maxes, int n, float log2_target, float* gscale, wm_stream_t stream);
 
 /* weight gradient of that ConvTranspose1d (= wm_wgrad64 with KW 7, gpro 0, layout 1): dw [in][out][7], dbias [64];
  * xpro 0 | 2 (x + vec[b*64+c]); partial: >= 256 * (7*4096 + 64) floats. */

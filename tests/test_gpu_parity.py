@@ -546,6 +546,44 @@ def test_convT_f16_split_is_fp32_grade(awm, dev, gscale):
     assert ops.gscale_absmax(torch.zeros(1024, device=dev)).cpu().tolist() == [1.0, 1.0]
 
 
+def test_convT_gradient_scale_comes_from_its_producer(awm, dev, monkeypatch):
+    """in the Generator's backward the gradient entering ConvTranspose1d's backward is the decoder ResBlock's dx: its conv1-pair launch
+    leaves max |dx| per workgroup (wm_dwgrad64_bf dzmax, epi 2) and ConvT7Fn takes its f16 scale from there (wm_gscale_from_max) -- no
+    streaming pass over the gradient (wm_gscale_absmax); both routes give the same power of two."""
+    from awm_amd import ops
+    G, _, _, _ = make_models(awm, dev)
+    G.train()
+    s = O.synthetic_clips(2, seed=70, T=2048).to(dev)
+    msg = O.synthetic_messages(2, seed=71).to(dev)
+    calls = {"from_max": [], "absmax": 0}
+    o1, o2 = awm.lib.wm_gscale_from_max, awm.lib.wm_gscale_absmax
+
+    def spy1(*a):
+        o1(*a)
+        calls["from_max"].append(a)
+
+    def spy2(*a):
+        calls["absmax"] += 1
+        return o2(*a)
+    monkeypatch.setattr(awm.lib, "wm_gscale_from_max", spy1)
+    monkeypatch.setattr(awm.lib, "wm_gscale_absmax", spy2)
+    seen, used = [], []
+    orig_of = ops.gscale_of
+
+    def of(g, *a):
+        seen.append(g.detach().clone())
+        used.append(orig_of(g, *a))
+        return used[-1]
+    monkeypatch.setattr(ops, "gscale_of", of)
+    G(s, msg).square().sum().backward()
+    assert len(calls["from_max"]) == 1 and calls["absmax"] == 0, calls
+    assert len(seen) == 1 and calls["from_max"][0][1] == 256
+    # the scale the backward used = the scale a pass over the same gradient gives
+    want = ops.gscale_absmax(seen[0]).cpu()
+    assert calls["absmax"] == 1
+    assert torch.equal(used[0].cpu(), want), (used[0], want)
+
+
 # ------------------------------------------------------------------------------------------ LSTM
 @pytest.mark.parametrize("B,T", [(2, 48), (1, 100), (3, 1000)])
 def test_lstm_small(awm, dev, B, T):
