@@ -97,6 +97,8 @@ timeit("lstm bwd fused (+dx)", lambda: lib.wm_lstm_bwd_fused(_p(xp), _p(cst), _p
 timeit("lstm_dx", lambda: lib.wm_lstm_dx(_p(xp), _p(wi), _p(y), B, T, st), FL, 5 * FR, n=3)
 lpart = _f32(256 * (256 * 128 + 256), device=dev); dwi = torch.empty_like(wi); dwh = torch.empty_like(wh); dbi = _f32(256, device=dev); dbh = _f32(256, device=dev)
 timeit("lstm_wgrad", lambda: lib.wm_lstm_wgrad(_p(xp), _p(x), _p(h), _p(lpart), _p(dwi), _p(dwh), _p(dbi), _p(dbh), B, T, 0, st), 2 * FL, 6 * FR, n=3)
+lpart2 = _f32(B * (256 * 128 + 256), device=dev)
+timeit("lstm_bwd_wgrad (recurrence + helper waves: dW_ih dW_hh db)", lambda: lib.wm_lstm_bwd_wgrad(_p(xp), _p(cst), _p(x2), _p(wh), _p(x), _p(h), _p(lpart2), _p(dwi), _p(dwh), _p(dbi), _p(dbh), B, T, 0, st), None, None, n=2)
 # heads / stem (Detector-side: 2B clips)
 s = torch.randn(2 * B, 1, T, device=dev); ws = torch.randn(64, 1, 7, device=dev); X2 = torch.randn(2 * B, 64, T, device=dev); Y2 = torch.empty_like(X2)
 timeit("stem_fwd (2B)", lambda: lib.wm_stem_fwd(_p(s), _p(ws), _p(bias), _p(Y2), 2 * B, T, st), None, 2 * FR)
