@@ -1363,8 +1363,11 @@ struct RbeArgs {
     int B, T;
 };
 
+// H = true: f16 two-piece build (three products per product): w1 / w2 = wm_pack_w64_h_scaled images (w * sc[out] * ws, {ws, 1 / ws} behind
+// the image), x and the intermediate a1 split into hi / lo f16 pieces unscaled, accumulators times 1 / ws in both epilogues
+template <bool H>
 __global__ __launch_bounds__(256) void resblock_eval_kernel(RbeArgs a) {
-    constexpr int KW = 3, NTO = 124, ROWS = 130, PITCH = 72, NP = 3, NC = 4;
+    constexpr int KW = 3, NTO = 124, ROWS = 130, PITCH = 72, NP = H ? 2 : 3, NC = 4;
     constexpr int XBUF = NP * ROWS * PITCH;               // bf16 elements per image
     extern __shared__ __align__(16) unsigned char smem_raw[];
     unsigned short* Xb = reinterpret_cast<unsigned short*>(smem_raw);              // x window: row r = time w0 + r
@@ -1376,7 +1379,7 @@ __global__ __launch_bounds__(256) void resblock_eval_kernel(RbeArgs a) {
     const int T = a.T;
     const int tilesPerClip = (T + 2 + NTO - 1) / NTO, ntiles = a.B * tilesPerClip;
 
-    bf16x8 W1[12][NP], W2[12][NP];
+    u32x4 W1[12][NP], W2[12][NP];
     {
         const uint4* wg1 = reinterpret_cast<const uint4*>(a.w1);
         const uint4* wg2 = reinterpret_cast<const uint4*>(a.w2);
@@ -1389,10 +1392,12 @@ __global__ __launch_bounds__(256) void resblock_eval_kernel(RbeArgs a) {
                 // 288 fragment registers do not fit the 256 VGPRs, and fragments the allocator spills are copied back per use
                 u32x4 w2_ = __builtin_bit_cast(u32x4, wg2[e >> 3]);
                 asm volatile("" : "+a"(w2_));
-                W1[s][p] = __builtin_bit_cast(bf16x8, wg1[e >> 3]);
-                W2[s][p] = __builtin_bit_cast(bf16x8, w2_);
+                W1[s][p] = __builtin_bit_cast(u32x4, wg1[e >> 3]);
+                W2[s][p] = w2_;
             }
     }
+    const float winv1 = H ? reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(a.w1) + NP * KW * 4096)[1] : 1.f;
+    const float winv2 = H ? reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(a.w2) + NP * KW * 4096)[1] : 1.f;
     // staging map (fixed per thread): channel pair cp, time quads q0 + 8 i
     const int cp = wave * 8 + (lane & 7), c0 = 2 * cp, q0 = lane >> 3;
     float4 sa[NC], sb[NC];
@@ -1410,11 +1415,17 @@ __global__ __launch_bounds__(256) void resblock_eval_kernel(RbeArgs a) {
         float va = (e == 0) ? fa.x : (e == 1) ? fa.y : (e == 2) ? fa.z : fa.w;
         float vb = (e == 0) ? fb.x : (e == 1) ? fb.y : (e == 2) ? fb.z : fb.w;
         va = ok ? va : 0.f; vb = ok ? vb : 0.f;
-        unsigned p0, p1, p2;
-        split3_pair(va, vb, p0, p1, p2);
         unsigned* X32 = reinterpret_cast<unsigned*>(Xb);
         const int o = (4 * (q0 + 8 * i) + e) * (PITCH / 2) + cp;
-        X32[o] = p0; X32[(ROWS * PITCH >> 1) + o] = p1; X32[2 * (ROWS * PITCH >> 1) + o] = p2;
+        if (H) {
+            const h16x2 h_ = __builtin_convertvector(f32x2{va, vb}, h16x2);
+            const h16x2 l_ = __builtin_convertvector(f32x2{va - (float)h_.x, vb - (float)h_.y}, h16x2);
+            X32[o] = __builtin_bit_cast(unsigned, h_); X32[(ROWS * PITCH >> 1) + o] = __builtin_bit_cast(unsigned, l_);
+        } else {
+            unsigned p0, p1, p2;
+            split3_pair(va, vb, p0, p1, p2);
+            X32[o] = p0; X32[(ROWS * PITCH >> 1) + o] = p1; X32[2 * (ROWS * PITCH >> 1) + o] = p2;
+        }
     };
 
     const int tstep = gridDim.x;
@@ -1461,38 +1472,60 @@ __global__ __launch_bounds__(256) void resblock_eval_kernel(RbeArgs a) {
     // in one lump in front of six back-to-back MFMAs).
 #define FENCE __builtin_amdgcn_sched_barrier(0)
     auto nop = []() {};
-    auto kstep = [&](const bf16x8 (&W)[12][NP], const unsigned short* img, f32x16& ac, bf16x8 (&Bq)[2][NP], int nt, int s,
+    auto mma = [&](const u32x4& A_, const u32x4& B_, f32x16 c) -> f32x16 {
+        if (H) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, A_), __builtin_bit_cast(h16x8, B_), c, 0, 0, 0);
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A_), __builtin_bit_cast(bf16x8, B_), c, 0, 0, 0);
+    };
+    auto kstep = [&](const u32x4 (&W)[12][NP], const unsigned short* img, f32x16& ac, u32x4 (&Bq)[2][NP], int nt, int s,
                      auto&& f0, auto&& f1, auto&& f2, auto&& f3, auto&& f4, auto&& f5) __attribute__((always_inline)) {
         if (s + 1 < 12) {
 #pragma unroll
             for (int p = 0; p < NP; ++p)
-                Bq[(s + 1) & 1][p] = *reinterpret_cast<const bf16x8*>(img + (p * ROWS + 32 * nt + ((s + 1) >> 2)) * PITCH + 16 * ((s + 1) & 3));
+                Bq[(s + 1) & 1][p] = *reinterpret_cast<const u32x4*>(img + (p * ROWS + 32 * nt + ((s + 1) >> 2)) * PITCH + 16 * ((s + 1) & 3));
         }
-        const bf16x8* Bf = Bq[s & 1];
+        const u32x4* Bf = Bq[s & 1];
         FENCE;
-        ac = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[s][1], Bf[1], ac, 0, 0, 0); FENCE; f0(); FENCE;
-        ac = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[s][0], Bf[2], ac, 0, 0, 0); FENCE; f1(); FENCE;
-        ac = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[s][2], Bf[0], ac, 0, 0, 0); FENCE; f2(); FENCE;
-        ac = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[s][0], Bf[1], ac, 0, 0, 0); FENCE; f3(); FENCE;
-        ac = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[s][1], Bf[0], ac, 0, 0, 0); FENCE; f4(); FENCE;
-        ac = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[s][0], Bf[0], ac, 0, 0, 0); FENCE; f5(); FENCE;
+        if (H) {                                         // lo hi, hi lo, hi hi: two slices behind every MFMA
+            ac = mma(W[s][1], Bf[0], ac); FENCE; f0(); FENCE; f1(); FENCE;
+            ac = mma(W[s][0], Bf[1], ac); FENCE; f2(); FENCE; f3(); FENCE;
+            ac = mma(W[s][0], Bf[0], ac); FENCE; f4(); FENCE; f5(); FENCE;
+        } else {
+            ac = mma(W[s][1], Bf[1], ac); FENCE; f0(); FENCE;
+            ac = mma(W[s][0], Bf[NP - 1], ac); FENCE; f1(); FENCE;
+            ac = mma(W[s][NP - 1], Bf[0], ac); FENCE; f2(); FENCE;
+            ac = mma(W[s][0], Bf[1], ac); FENCE; f3(); FENCE;
+            ac = mma(W[s][1], Bf[0], ac); FENCE; f4(); FENCE;
+            ac = mma(W[s][0], Bf[0], ac); FENCE; f5(); FENCE;
+        }
     };
     // the bf16x3 split of a value pair in three stages (one slice each)
     float sva = 0.f, svb = 0.f;
     unsigned sp0 = 0, sp1 = 0, sp2 = 0;
     auto st1 = [&]() {
-        const bf16x2 h = {(__bf16)sva, (__bf16)svb};
-        sp0 = __builtin_bit_cast(unsigned, h);
-        sva -= __uint_as_float(sp0 << 16); svb -= __uint_as_float(sp0 & 0xffff0000u);
+        if (H) {
+            const h16x2 h = __builtin_convertvector(f32x2{sva, svb}, h16x2);
+            sp0 = __builtin_bit_cast(unsigned, h);
+            sva -= (float)h.x; svb -= (float)h.y;
+        } else {
+            const bf16x2 h = {(__bf16)sva, (__bf16)svb};
+            sp0 = __builtin_bit_cast(unsigned, h);
+            sva -= __uint_as_float(sp0 << 16); svb -= __uint_as_float(sp0 & 0xffff0000u);
+        }
         asm volatile("" : "+v"(sva), "+v"(svb), "+v"(sp0));      // pins the stage into its slice (pure arithmetic sinks to its use otherwise)
     };
     auto st2 = [&]() {
+        if (H) return;                                   // two pieces: no middle one
         const bf16x2 m = {(__bf16)sva, (__bf16)svb};
         sp1 = __builtin_bit_cast(unsigned, m);
         sva -= __uint_as_float(sp1 << 16); svb -= __uint_as_float(sp1 & 0xffff0000u);
         asm volatile("" : "+v"(sva), "+v"(svb), "+v"(sp1));
     };
     auto st3 = [&](unsigned* img32, int o) {
+        if (H) {
+            sp2 = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{sva, svb}, h16x2));
+            img32[o] = sp0; img32[(ROWS * PITCH >> 1) + o] = sp2;
+            return;
+        }
         const bf16x2 l = {(__bf16)sva, (__bf16)svb};
         sp2 = __builtin_bit_cast(unsigned, l);
         img32[o] = sp0; img32[(ROWS * PITCH >> 1) + o] = sp1; img32[2 * (ROWS * PITCH >> 1) + o] = sp2;
@@ -1522,7 +1555,8 @@ __global__ __launch_bounds__(256) void resblock_eval_kernel(RbeArgs a) {
         // epilogue 1 of accumulator pair pi (rows 2 pi, 2 pi + 1 = two adjacent channels) of block nt, in slices:
         // BN1 offset + ReLU + zero padding -> split stages -> a1 image
         auto e1_act = [&](const f32x16& ac, int nt, int pi) {
-            const float v0 = fmaxf(ac[2 * pi] + k1[2 * pi], 0.f), v1 = fmaxf(ac[2 * pi + 1] + k1[2 * pi + 1], 0.f);
+            const float v0 = fmaxf(H ? fmaf(ac[2 * pi], winv1, k1[2 * pi]) : ac[2 * pi] + k1[2 * pi], 0.f),
+                        v1 = fmaxf(H ? fmaf(ac[2 * pi + 1], winv1, k1[2 * pi + 1]) : ac[2 * pi + 1] + k1[2 * pi + 1], 0.f);
             sva = in1[nt] ? v0 : 0.f; svb = in1[nt] ? v1 : 0.f;
             asm volatile("" : "+v"(sva), "+v"(svb));
         };
@@ -1543,19 +1577,19 @@ __global__ __launch_bounds__(256) void resblock_eval_kernel(RbeArgs a) {
         auto x_out = [&](int i, int e) { st3(X32, (4 * (q0 + 8 * i) + e) * (PITCH / 2) + cp); };
         // epilogue 2 of accumulator row r of block nt: BN2 offset + residual + ReLU + store
         auto e2_value = [&](const f32x16& ac, int nt, int r) {
-            const float v = fmaxf(e1r[nt * 16 + r] + (ac[r] + k2[r]), 0.f);
+            const float v = fmaxf(e1r[nt * 16 + r] + (H ? fmaf(ac[r], winv2, k2[r]) : ac[r] + k2[r]), 0.f);
             buf_store(syr, v, tcl[nt], roff(r));
         };
 
         f32x16 acc[2];
-        bf16x8 Bq[2][NP];
+        u32x4 Bq[2][NP];
         STAMP(ts0);
         // ---------------- conv1 from the x image
         const unsigned short* xrow = Xb + (64 * nh + l31) * PITCH + 8 * half;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
 #pragma unroll
-        for (int p = 0; p < NP; ++p) Bq[0][p] = *reinterpret_cast<const bf16x8*>(xrow + p * ROWS * PITCH);
+        for (int p = 0; p < NP; ++p) Bq[0][p] = *reinterpret_cast<const u32x4*>(xrow + p * ROWS * PITCH);
         // column block 0; side work: fetch the next tile's x window (split during conv2)
 #pragma unroll
         for (int s = 0; s < 12; ++s) {
@@ -1564,7 +1598,7 @@ __global__ __launch_bounds__(256) void resblock_eval_kernel(RbeArgs a) {
         }
         STAMP(ts1);
 #pragma unroll
-        for (int p = 0; p < NP; ++p) Bq[0][p] = *reinterpret_cast<const bf16x8*>(xrow + (p * ROWS + 32) * PITCH);
+        for (int p = 0; p < NP; ++p) Bq[0][p] = *reinterpret_cast<const u32x4*>(xrow + (p * ROWS + 32) * PITCH);
         // column block 1; side work: epilogue 1 of block 0
 #pragma unroll
         for (int s = 0; s < 12; ++s) {
@@ -1584,7 +1618,7 @@ __global__ __launch_bounds__(256) void resblock_eval_kernel(RbeArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
 #pragma unroll
-        for (int p = 0; p < NP; ++p) Bq[0][p] = *reinterpret_cast<const bf16x8*>(arow + p * ROWS * PITCH);
+        for (int p = 0; p < NP; ++p) Bq[0][p] = *reinterpret_cast<const u32x4*>(arow + p * ROWS * PITCH);
         // column block 0; side work: first half of the next tile's x window, residual operand of block 0
 #pragma unroll
         for (int s = 0; s < 12; ++s) {
@@ -1594,7 +1628,7 @@ __global__ __launch_bounds__(256) void resblock_eval_kernel(RbeArgs a) {
             else kstep(W2, arow, acc[0], Bq, 0, s, nop, nop, nop, nop, nop, nop);
         }
 #pragma unroll
-        for (int p = 0; p < NP; ++p) Bq[0][p] = *reinterpret_cast<const bf16x8*>(arow + (p * ROWS + 32) * PITCH);
+        for (int p = 0; p < NP; ++p) Bq[0][p] = *reinterpret_cast<const u32x4*>(arow + (p * ROWS + 32) * PITCH);
         // column block 1; side work: second half of the window, residual operand of block 1, epilogue 2 of block 0
 #pragma unroll
         for (int s = 0; s < 12; ++s) {
@@ -1629,16 +1663,17 @@ __global__ __launch_bounds__(256) void resblock_eval_kernel(RbeArgs a) {
 #endif
 }
 
+template <bool H>
 static int launch_resblock_eval(const RbeArgs& a, hipStream_t stream) {
-    constexpr size_t lds = (size_t)(2 * 3 * 130 * 72) * 2 + 2 * 64 * sizeof(float);
+    constexpr size_t lds = (size_t)(2 * (H ? 2 : 3) * 130 * 72) * 2 + 2 * 64 * sizeof(float);
     static wm::DevOnce attr_done;
     if (!wm::dev_done(attr_done)) {
-        WM_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(resblock_eval_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        WM_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(resblock_eval_kernel<H>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         wm::dev_mark(attr_done);
     }
     const int ntiles = a.B * ((a.T + 2 + 123) / 124);
     const int grid = ntiles < kNumCU ? ntiles : kNumCU;
-    hipLaunchKernelGGL(resblock_eval_kernel, dim3(grid), dim3(256), lds, stream, a);
+    hipLaunchKernelGGL(resblock_eval_kernel<H>, dim3(grid), dim3(256), lds, stream, a);
     WM_CHECK_LAUNCH();
     return 0;
 }
@@ -3032,7 +3067,8 @@ int launch_wgrad64bf7(const Wgrad64Args& a, int* grid_out, hipStream_t stream) {
 
 // f16 two-piece image of a k3 weight for dwgrad64bf_kernel<..., H = true>: [2 pieces][3 taps][64 out][64 in] f16 of w * ws, ws = the power
 // of two that brings max |w| to [2^9, 2^10), followed by {ws, 1 / ws} as two floats.  One workgroup (12 288 values).
-__global__ __launch_bounds__(1024) void pack_w64_h_kernel(const float* __restrict__ w, unsigned short* __restrict__ wph, int mode) {
+__global__ __launch_bounds__(1024) void pack_w64_h_kernel(const float* __restrict__ w, const float* __restrict__ row_scale,
+                                                          unsigned short* __restrict__ wph, int mode) {
     __shared__ float red[16];
     float v[12];                                    // the thread's 12 of the 12 288 values: one trip to memory
     float mx = 0.f;
@@ -3040,6 +3076,7 @@ __global__ __launch_bounds__(1024) void pack_w64_h_kernel(const float* __restric
     for (int j = 0; j < 12; ++j) {
         const int i = threadIdx.x + 1024 * j, tap = i / 4096, out = (i / 64) % 64, in = i % 64;
         v[j] = (mode == 0) ? w[(out * 64 + in) * 3 + tap] : w[(in * 64 + out) * 3 + (2 - tap)];
+        if (row_scale) v[j] *= row_scale[out];      // a per-output-channel factor (folded BatchNorm scale) rides in the weights
         mx = fmaxf(mx, fabsf(v[j]));
     }
 #pragma unroll
@@ -3960,11 +3997,11 @@ int wm_conv64_bf(const float* x, const float* x2, const void* wpb, const float* 
 
 // inference ResBlock in one launch (both BatchNorms folded): see resblock_eval_kernel
 int wm_resblock_eval_bf(const float* x, const void* w1pb, const void* w2pb, const float* b1, const float* sc1, const float* sh1,
-                        const float* b2, const float* sc2, const float* sh2, float* y, int B, int T, hipStream_t stream) {
-    if (B <= 0 || T <= 0 || (T & 3)) return (int)hipErrorInvalidValue;
+                        const float* b2, const float* sc2, const float* sh2, float* y, int B, int T, int arith, hipStream_t stream) {
+    if (B <= 0 || T <= 0 || (T & 3) || (arith != 0 && arith != 1)) return (int)hipErrorInvalidValue;
     if (!x || !w1pb || !w2pb || !sc1 || !sh1 || !sc2 || !sh2 || !y) return (int)hipErrorInvalidValue;
     RbeArgs a{x, w1pb, w2pb, b1, sc1, sh1, b2, sc2, sh2, y, B, T};
-    return launch_resblock_eval(a, stream);
+    return arith == 1 ? launch_resblock_eval<true>(a, stream) : launch_resblock_eval<false>(a, stream);
 }
 
 // bf16x6 build of the 7-tap ConvTranspose1d (forward: mode 2 image, pro 0|2, epi 0; data gradient: mode 3 image, pro 0, epi 3)
@@ -4052,7 +4089,14 @@ int wm_wgrad64_bf(const float* g, const float* g2, const float* ga, const float*
 // f16 two-piece weight image for wm_dwgrad64_bf arith 1: 2 * 3 * 4096 f16 + 2 floats (mode 0 forward | 1 data gradient, as wm_pack_w64_bf)
 int wm_pack_w64_h(const float* w, void* wph, int mode, hipStream_t stream) {
     if (!w || !wph || mode < 0 || mode > 1) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(pack_w64_h_kernel, dim3(1), dim3(1024), 0, stream, w, reinterpret_cast<unsigned short*>(wph), mode);
+    hipLaunchKernelGGL(pack_w64_h_kernel, dim3(1), dim3(1024), 0, stream, w, (const float*)nullptr, reinterpret_cast<unsigned short*>(wph), mode);
+    WM_CHECK_LAUNCH();
+    return 0;
+}
+// forward image (mode 0) of w[out][in][k] * row_scale[out] (wm_resblock_eval_bf arith 1)
+int wm_pack_w64_h_scaled(const float* w, const float* row_scale, void* wph, hipStream_t stream) {
+    if (!w || !row_scale || !wph) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(pack_w64_h_kernel, dim3(1), dim3(1024), 0, stream, w, row_scale, reinterpret_cast<unsigned short*>(wph), 0);
     WM_CHECK_LAUNCH();
     return 0;
 }

@@ -152,7 +152,8 @@ _CONV = {"bf16x6": _os.environ.get("WM_CONV_BF16X6", "1") == "1", "schedule": 2,
          "pair_fold": _os.environ.get("WM_PAIR_FOLD", "1") == "1",
          "bwd_f16x3": _os.environ.get("WM_BWD_F16X3", "1") == "1",
          "fwd_f16x3": _os.environ.get("WM_FWD_F16X3", "1") == "1",
-         "conv7_f16x3": _os.environ.get("WM_CONV7_F16X3", "1") == "1"}
+         "conv7_f16x3": _os.environ.get("WM_CONV7_F16X3", "1") == "1",
+         "eval_f16x3": _os.environ.get("WM_EVAL_F16X3", "1") == "1"}
 
 
 def set_conv_bf_schedule(schedule: int):
@@ -191,8 +192,13 @@ def set_bwd_f16x3(on: bool):
 def set_fwd_f16x3(on: bool):
     """ResBlock forward convolutions launched through wm_conv64_bf (schedule 2, T % 128 == 0): 1 (default) the f16 two-piece split
     (three products per product instead of six; weights scaled by a power of two from max |w|, activations unscaled), 0 bf16x6.
-    WM_FWD_F16X3=0/1 sets the default.  The one-launch inference ResBlock (wm_resblock_eval_bf) is bf16x6 either way."""
+    WM_FWD_F16X3=0/1 sets the default.  The one-launch inference ResBlock has its own switch (set_eval_f16x3)."""
     _CONV["fwd_f16x3"] = bool(on)
+
+
+def set_eval_f16x3(on: bool):
+    """one-launch inference ResBlock (wm_resblock_eval_bf): 1 (default) the f16 two-piece split, 0 bf16x6.  WM_EVAL_F16X3=0/1."""
+    _CONV["eval_f16x3"] = bool(on)
 
 
 def pack_w64_h(w: torch.Tensor, mode: int) -> torch.Tensor:
@@ -315,11 +321,14 @@ class ResBlockFn(GradAwareFunction):
             lib.wm_bn_eval_scale_shift(_p(g2), _p(be2), _p(rm2), _p(rv2), BN_EPS, _p(sc2), _p(sh2), st)
             if not wants_grad(ctx) and _CONV["bf16x6"] and _CONV["one_launch_eval"]:
                 # inference: the whole block is ONE launch -- x in, out out, the intermediate activation stays in LDS
-                wp1 = torch.empty(3 * 3 * 4096, dtype=torch.int16, device=dev)          # both images must be alive at the launch
+                h = _CONV["eval_f16x3"]                     # f16 two-piece split (three products per product) | bf16x6
+                wp1 = torch.empty((2 * 3 * 4096 + 4) if h else 3 * 3 * 4096, dtype=torch.int16, device=dev)   # both images alive at the launch
                 wp2 = torch.empty_like(wp1)
-                lib.wm_pack_w64_bf_scaled(_p(w1), _p(sc1), _p(wp1), st)
-                lib.wm_pack_w64_bf_scaled(_p(w2), _p(sc2), _p(wp2), st)
-                lib.wm_resblock_eval_bf(_p(x), _p(wp1), _p(wp2), _p(b1), _p(sc1), _p(sh1), _p(b2), _p(sc2), _p(sh2), _p(out), B, T, st)
+                pack = lib.wm_pack_w64_h_scaled if h else lib.wm_pack_w64_bf_scaled
+                pack(_p(w1), _p(sc1), _p(wp1), st)
+                pack(_p(w2), _p(sc2), _p(wp2), st)
+                lib.wm_resblock_eval_bf(_p(x), _p(wp1), _p(wp2), _p(b1), _p(sc1), _p(sh1), _p(b2), _p(sc2), _p(sh2), _p(out), B, T,
+                                        1 if h else 0, st)
                 return out
             y1 = torch.empty_like(x)
             _conv3(x, None, w1, 0, None, None, None, b1, None, None, None, y1, None, B, T, 0, 0)

@@ -289,8 +289,10 @@ def kernel_timers(lib, model, mode, bf_mode, batch):
         return [dict(timer=LaunchTimer(lib, "wm_resblock_eval_bf", lambda a: True,
                                        lambda a: (2.0 * 2.0 * 64 * 64 * 3 * a[11] * a[10], 2.0 * 64 * a[11] * 4 * a[10])),
                      kernel="resblock_eval_kernel (wm_resblock_eval_bf: the inference ResBlock in one launch -- conv1 + BN1 + ReLU, the "
-                            "intermediate kept in LDS as bf16x3 pieces, conv2 + BN2 + residual + ReLU; bf16x6 split products)",
-                     peak=BF16X6_PEAK, note=BF16X6_NOTE, pmc=None, pmc_prefixes=())]
+                            "intermediate kept in LDS as split pieces, conv2 + BN2 + residual + ReLU; " +
+                            ("f16 two-piece split, three piece products per product)" if _ops._CONV["eval_f16x3"] else "bf16x6 split products)"),
+                     peak=(PEAK_BF16_MFMA_TFLOPS / 3.0) if _ops._CONV["eval_f16x3"] else BF16X6_PEAK,
+                     note=F16X3_NOTE if _ops._CONV["eval_f16x3"] else BF16X6_NOTE, pmc=None, pmc_prefixes=())]
     if not _ops._CONV["fused_bwd"]:
         return [fwd]
     # ResBlock backward: data gradient + weight gradient of one Conv1d(64,64,3) in ONE launch = two GEMMs of 2*64*64*3*T*B flops.

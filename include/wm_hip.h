@@ -78,7 +78,10 @@ int wm_conv64_bf(const float* x, const float* x2, const void* wpb, const float* 
  * Two frame passes over HBM (x in, y out): the intermediate activation stays in LDS as bf16x3 pieces.  T % 4 == 0. */
 int wm_pack_w64_bf_scaled(const float* w, const float* row_scale, void* wpb, wm_stream_t stream);
 int wm_resblock_eval_bf(const float* x, const void* w1pb, const void* w2pb, const float* b1, const float* sc1, const float* sh1,
-                        const float* b2, const float* sc2, const float* sh2, float* y, int B, int T, wm_stream_t stream);
+                        const float* b2, const float* sc2, const float* sh2, float* y, int B, int T, int arith, wm_stream_t stream);
+/* arith 0: bf16x6 (images from wm_pack_w64_bf_scaled).  arith 1: f16 two-piece split, three products per product; images from
+ * wm_pack_w64_h_scaled (w * sc[out] * ws, {ws, 1 / ws} behind the image), x and the intermediate split unscaled. */
+int wm_pack_w64_h_scaled(const float* w, const float* row_scale, void* wph, wm_stream_t stream);
 
 /* Data gradient AND weight gradient of a 64->64 k3 convolution in ONE launch (ResBlock backward, py/main16.py:112-125 under
  * autograd): g = ga[c] dz + gb[c] + gb[64+c] + gc[c] y is rebuilt once and feeds both; frames moved: 4 (conv2 pair) / 5 (conv1

@@ -14,7 +14,7 @@ vp = ctypes.c_void_p
 L.wm_debug_set_stamp_buffer(vp(buf.data_ptr()))
 wp1 = torch.empty(3 * 3 * 4096, dtype=torch.int16, device=dev); wp2 = torch.empty_like(wp1)
 L.wm_pack_w64_bf_scaled(vp(w1.data_ptr()), vp(c[1].data_ptr()), vp(wp1.data_ptr()), None); L.wm_pack_w64_bf_scaled(vp(w2.data_ptr()), vp(c[4].data_ptr()), vp(wp2.data_ptr()), None)
-args = [vp(x.data_ptr()), vp(wp1.data_ptr()), vp(wp2.data_ptr())] + [vp(t.data_ptr()) for t in c] + [vp(y.data_ptr()), B, T, None]
+args = [vp(x.data_ptr()), vp(wp1.data_ptr()), vp(wp2.data_ptr())] + [vp(t.data_ptr()) for t in c] + [vp(y.data_ptr()), B, T, 0, None]
 e0, e1 = torch.cuda.Event(True), torch.cuda.Event(True)
 for _ in range(3):
     buf.zero_(); torch.cuda.synchronize(); e0.record(); rc = L.wm_resblock_eval_bf(*args); e1.record(); torch.cuda.synchronize()

@@ -194,6 +194,38 @@ def test_resblock_inference_fused_epilogue(awm, dev, B, T, one_launch):
     check_elementwise(y_fused, yr, "fused eval resblock (element-wise)")
 
 
+@pytest.mark.parametrize("B,T", [(2, 1280), (1, 16000), (3, 1000)])
+def test_resblock_eval_f16_split_matches_bf16x6(awm, dev, B, T):
+    """the one-launch inference ResBlock on the f16 two-piece split (wm_resblock_eval_bf arith 1: three products per product, BatchNorm
+    scales folded into the scaled weight image, x and the intermediate split unscaled) against its bf16x6 build on the same inputs
+    (within 2e-6 of max |y|: both are fp32-grade) and against the oracle (the tolerances of the bf16x6 test)."""
+    sd = _resblock_state(31 + B)
+    x = rnd(B, 64, T, seed=14).abs() * 0.7
+    m = awm.ResBlock(64)
+    m.load_state_dict(sd)
+    m.to(dev).eval()
+    ys, ar = [], []
+    orig = awm.lib.wm_resblock_eval_bf
+
+    def spy(*a):
+        ar.append(a[12])
+        return orig(*a)
+    awm.lib.wm_resblock_eval_bf = spy
+    try:
+        for h in (False, True):
+            awm.ops.set_eval_f16x3(h)
+            with torch.no_grad():
+                ys.append(m(x.to(dev)))
+    finally:
+        awm.lib.wm_resblock_eval_bf = orig
+        awm.ops.set_eval_f16x3(True)
+    assert ar == [0, 1], ar
+    assert rel_err(ys[1], ys[0]) < 2e-6, rel_err(ys[1], ys[0])
+    yr = O.resblock({k: v.clone() for k, v in sd.items()}, "", x, False, {})
+    check(ys[1], yr, FWD_TOL, "eval resblock, f16 split")
+    check_elementwise(ys[1], yr, "eval resblock, f16 split (element-wise)")
+
+
 def test_no_grad_lstm_skips_saved_activations(awm, dev):
     """under torch.no_grad() the LSTM must take the forward-only launch (no [B,T,256] gates / [B,T,64] cell-state
     tensors: 5 GB at B=256) although its weights require grad"""
