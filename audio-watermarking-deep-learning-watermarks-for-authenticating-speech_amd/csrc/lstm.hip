@@ -484,6 +484,169 @@ __global__ __launch_bounds__(256) void lstm_fwd_fused_kernel(const float* __rest
 #endif
 }
 
+// ------------------------------------------ recurrence fwd, wave-specialised: the input projection beside it
+// lstm_fwd_fused_kernel with the roles split over eight waves (as lstm_bwd_ws_kernel): waves 0..3 run the recurrence and nothing else;
+// waves 4..7 -- the second wave of each SIMD -- compute chunk c+1's projection [32 steps x 256 gate rows] on the matrix cores (bf16x6,
+// W_ih fragments in THEIR registers: the recurrence waves lose 96 registers, 48 MFMAs, the x split and the table stores per chunk)
+// into the other half of the double-buffered LDS table.  The helpers execute the recurrence's one barrier per step and use those
+// barriers as their own phase separators: slot 0 of a chunk splits the x tile into the LDS image, slots 1..24 issue two MFMAs each,
+// slot 26 stores the table.  Same arithmetic and summation order as the fused kernel: bit-identical results.
+template <bool SAVE>
+__global__ __launch_bounds__(512) void lstm_fwd_ws_kernel(const float* __restrict__ x, const float* __restrict__ w_ih,
+                                                          const float* __restrict__ b_ih, const float* __restrict__ b_hh,
+                                                          const float* __restrict__ w_hh, float* __restrict__ hout,
+                                                          float* __restrict__ gates, float* __restrict__ cst, int T) {
+    constexpr int CH = 32, XPP = 257, PITCH = 72, NP = 3;
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    float* xps = reinterpret_cast<float*>(smem_raw);                                  // [2][CH][XPP]
+    unsigned short* Xb = reinterpret_cast<unsigned short*>(xps + 2 * CH * XPP);       // [NP][CH][PITCH]
+    float* hsm = reinterpret_cast<float*>(Xb + NP * CH * PITCH);                      // [2][64]
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (wave < 4) {
+        // ------------------------------------------------------------------ the recurrence
+        __builtin_amdgcn_s_setprio(3);
+        const int q = lane & 3, ul = lane >> 2, u = wave * 16 + ul, n = q * 64 + u, np = wave * 64 + lane;
+        float wr[64];                                  // W_hh row n of this lane
+#pragma unroll
+        for (int k = 0; k < 64; k += 4) {
+            const float4 v = *reinterpret_cast<const float4*>(w_hh + n * 64 + k);
+            wr[k] = v.x; wr[k + 1] = v.y; wr[k + 2] = v.z; wr[k + 3] = v.w;
+        }
+        const float bias = b_ih[n] + b_hh[n];
+        if (tid < 128) hsm[tid] = 0.f;
+        float c = 0.f;
+        const wm_srd_t sgb = make_srd(SAVE ? gates + (size_t)b * T * 256 : hout, SAVE ? (size_t)T * 256 * sizeof(float) : 0);
+        const wm_srd_t scb = make_srd(SAVE ? cst + (size_t)b * T * 64 : hout, SAVE ? (size_t)T * 64 * sizeof(float) : 0);
+        const wm_srd_t shb = make_srd(hout + (size_t)b * 64 * T, (size_t)64 * T * sizeof(float));
+        const unsigned vgb = (unsigned)np * 4u, vcb = (q == 1) ? (unsigned)u * 4u : 0xFFFFFF00u;
+        const unsigned vhb = (unsigned)(u * T + 4 * q) * 4u;
+        float* hb = hout + ((size_t)b * 64 + u) * T;
+        const bool is_g = (q == 2);
+        __syncthreads(); __syncthreads(); __syncthreads();          // the helpers' prologue: projection of chunk 0
+        float hk[4];
+        int t0 = 0, cbuf = 0;
+        auto run8 = [&](auto sub_c) {
+            constexpr int SUB = decltype(sub_c)::value;
+#pragma unroll
+            for (int j8 = 0; j8 < 8; ++j8) {
+                const int s = SUB * 8 + j8;
+                const int t = t0 + s;
+                if (t < T) {                                   // uniform across the workgroup
+                    const float xin = xps[(cbuf * CH + s) * XPP + np] + bias;
+                    const float* hcur = hsm + (s & 1) * 64;
+                    const float4 hq4 = *reinterpret_cast<const float4*>(hcur + 4 * (lane & 15));   // h(t-1), row-replicated
+                    const float Hh[4] = {hq4.x, hq4.y, hq4.z, hq4.w};
+                    const float pre = dot64_rowbcast(Hh, wr, xin);
+                    const float act = gate_act(pre, is_g);
+                    const float gi = quad_bcast<0>(act), gf = quad_bcast<1>(act), gg = quad_bcast<2>(act), go = quad_bcast<3>(act);
+                    c = fmaf(gf, c, gi * gg);
+                    const float h = go * tanh_s(c);
+                    hsm[((s + 1) & 1) * 64 + rowbcast_slot(u)] = h;
+                    if (SAVE) {
+                        buf_store(sgb, act, vgb, (unsigned)t * 1024u);
+                        buf_store(scb, c, vcb, (unsigned)t * 256u);
+                    }
+                    if (((s >> 2) & 3) == q) hk[s & 3] = h;
+                    if ((s & 15) == 15)
+                        buf_store4(shb, f32x4{hk[0], hk[1], hk[2], hk[3]}, vhb, (unsigned)(t0 + (s - 15)) * 4u);
+                    __syncthreads();
+                }
+            }
+        };
+        for (; t0 < T; t0 += CH, cbuf ^= 1) {
+            run8(std::integral_constant<int, 0>{});
+            run8(std::integral_constant<int, 1>{});
+            run8(std::integral_constant<int, 2>{});
+            run8(std::integral_constant<int, 3>{});
+            if (t0 + CH > T && (T & 15)) {                   // ragged tail: flush what the last partial 16-step group produced
+                const int g0 = (T >> 4) << 4, tq0 = g0 + 4 * q;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (tq0 + j < T) hb[tq0 + j] = hk[j];
+            }
+        }
+        return;
+    }
+    // ---------------------------------------------------------------------- the helpers: projection of the next chunk
+    const int hw = wave - 4;
+    bf16x8 Wi[2][4][NP];                                   // W_ih A fragments: row l31 of m-tile mt <-> gate column hw*64 + mt*32 + l31
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const float* wp = w_ih + gate_row(hw * 64 + mt * 32 + l31) * 64 + 16 * ks + 8 * half;
+            const float4 v0 = *reinterpret_cast<const float4*>(wp), v1 = *reinterpret_cast<const float4*>(wp + 4);
+            unsigned a[4], m[4], l[4];
+            split3_pair(v0.x, v0.y, a[0], m[0], l[0]); split3_pair(v0.z, v0.w, a[1], m[1], l[1]);
+            split3_pair(v1.x, v1.y, a[2], m[2], l[2]); split3_pair(v1.z, v1.w, a[3], m[3], l[3]);
+            Wi[mt][ks][0] = __builtin_bit_cast(bf16x8, make_uint4(a[0], a[1], a[2], a[3]));
+            Wi[mt][ks][1] = __builtin_bit_cast(bf16x8, make_uint4(m[0], m[1], m[2], m[3]));
+            Wi[mt][ks][2] = __builtin_bit_cast(bf16x8, make_uint4(l[0], l[1], l[2], l[3]));
+        }
+    const int cp = hw * 8 + (lane & 7), tq = lane >> 3;    // x tile staging: channel pair cp, time quad tq of the chunk
+    const float* xc = x + ((size_t)b * 64 + 2 * cp) * T + 4 * tq;
+    float4 sa, sb;
+    auto load_x = [&](int t0) {                    // clamped: chunks past the end re-read the last valid quad
+        const int t = min(t0, T - 4 - 4 * tq);
+        sa = *reinterpret_cast<const float4*>(xc + max(t, -4 * tq));
+        sb = *reinterpret_cast<const float4*>(xc + T + max(t, -4 * tq));
+    };
+    auto split_x = [&]() {
+        unsigned* X32 = reinterpret_cast<unsigned*>(Xb);
+        const float va[4] = {sa.x, sa.y, sa.z, sa.w}, vb[4] = {sb.x, sb.y, sb.z, sb.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            unsigned p0, p1, p2;
+            split3_pair(va[e], vb[e], p0, p1, p2);
+            const int o = (4 * tq + e) * (PITCH / 2) + cp;
+            X32[o] = p0; X32[CH * PITCH / 2 + o] = p1; X32[2 * (CH * PITCH / 2) + o] = p2;
+        }
+    };
+    f32x16 acc[2];
+    bf16x8 Bf[NP];
+    auto mfma_one = [&](int idx) {                 // idx-th of the 48 MFMAs of a chunk: block m = idx / 6 = ks * 2 + mt, piece product idx % 6
+        const int m = idx / 6, pr = idx % 6, ks = m >> 1, mt = m & 1;
+        const int pa = (pr == 0 || pr == 4) ? 1 : (pr == 2 ? 2 : 0), pb = (pr == 0 || pr == 3) ? 1 : (pr == 1 ? 2 : 0);
+        if (mt == 0 && pr == 0) {
+#pragma unroll
+            for (int p = 0; p < NP; ++p) Bf[p] = *reinterpret_cast<const bf16x8*>(Xb + (p * CH + l31) * PITCH + 16 * ks + 8 * half);
+        }
+        if (ks == 0 && pr == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+        }
+        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wi[mt][ks][pa], Bf[pb], acc[mt], 0, 0, 0);
+    };
+    auto store_xp = [&](int buf) {                 // D row = gate column (this wave's 64), D column = step
+        float* dst = xps + (buf * CH + l31) * XPP + hw * 64 + 4 * half;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dst[mt * 32 + (r & 3) + 8 * (r >> 2)] = acc[mt][r];
+    };
+    // ---- prologue: projection of chunk 0, x tile of chunk 1 in flight (three barriers, matched by the recurrence waves)
+    load_x(0);
+    __syncthreads();
+    split_x();
+    load_x(CH);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 48; ++i) mfma_one(i);
+    store_xp(0);
+    __syncthreads();
+    int cbuf = 0;
+    for (int t0 = 0; t0 < T; t0 += CH, cbuf ^= 1) {
+#pragma unroll
+        for (int s = 0; s < CH; ++s) {
+            if (s == 0) { split_x(); load_x(t0 + 2 * CH); }
+            if (s >= 1 && s <= 24) { mfma_one(2 * (s - 1)); mfma_one(2 * (s - 1) + 1); }
+            if (s == 26) store_xp(cbuf ^ 1);
+            if (t0 + s < T) __syncthreads();           // = the barrier of one recurrence step
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------- recurrence bwd
 // gates: in = saved activations, out = pre-activation gradients da  [B,T,256] (column order n' = unit*4 + gate)
 __global__ __launch_bounds__(256) void lstm_bwd_kernel(float* __restrict__ gates, const float* __restrict__ cst,
@@ -1380,6 +1543,9 @@ int wm_lstm_fwd(const float* xp, const float* w_hh, float* hout, float* gates, f
     return 0;
 }
 
+static int g_lstm_fwd_ws = 1;       // 1: lstm_fwd_ws_kernel (projection on helper waves) | 0: lstm_fwd_fused_kernel (inside the recurrence's waves)
+int wm_set_lstm_fwd_wave_specialised(int on, hipStream_t) { g_lstm_fwd_ws = on ? 1 : 0; return 0; }
+
 // Recurrence with the input projection inside (no xp tensor): x [B,64,T] -> hout; gates / cst as wm_lstm_fwd.
 int wm_lstm_fwd_fused(const float* x, const float* w_ih, const float* b_ih, const float* b_hh, const float* w_hh, float* hout,
                       float* gates, float* cst, int B, int T, hipStream_t stream) {
@@ -1390,6 +1556,18 @@ int wm_lstm_fwd_fused(const float* x, const float* w_ih, const float* b_ih, cons
         WM_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_fwd_fused_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         WM_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_fwd_fused_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         wm::dev_mark(done);
+    }
+    if (g_lstm_fwd_ws) {                            // wave-specialised build: the projection on four helper waves (default)
+        static wm::DevOnce donew;
+        if (!wm::dev_done(donew)) {
+            WM_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_fwd_ws_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            WM_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_fwd_ws_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            wm::dev_mark(donew);
+        }
+        if (gates && cst) hipLaunchKernelGGL(lstm_fwd_ws_kernel<true>, dim3(B), dim3(512), lds, stream, x, w_ih, b_ih, b_hh, w_hh, hout, gates, cst, T);
+        else hipLaunchKernelGGL(lstm_fwd_ws_kernel<false>, dim3(B), dim3(512), lds, stream, x, w_ih, b_ih, b_hh, w_hh, hout, gates, cst, T);
+        WM_CHECK_LAUNCH();
+        return 0;
     }
     if (gates && cst) hipLaunchKernelGGL(lstm_fwd_fused_kernel<true>, dim3(B), dim3(256), lds, stream, x, w_ih, b_ih, b_hh, w_hh, hout, gates, cst, T);
     else hipLaunchKernelGGL(lstm_fwd_fused_kernel<false>, dim3(B), dim3(256), lds, stream, x, w_ih, b_ih, b_hh, w_hh, hout, gates, cst, T);

@@ -592,7 +592,18 @@ class HeadNFn(torch.autograd.Function):
 # ------------------------------------------------------------------------------------------ LSTM
 _LSTM_FUSED = _os.environ.get("WM_LSTM_FUSED", "1") == "1"     # 0: separate wm_lstm_xproj + wm_lstm_fwd launches
 _LSTM_BWD_FUSED = _os.environ.get("WM_LSTM_BWD_FUSED", "0") == "1"   # 1: wm_lstm_bwd + wm_lstm_dx as one launch
-_LSTM = {"bwd_ws": _os.environ.get("WM_LSTM_BWD_WS", "1") == "1"}
+_LSTM = {"bwd_ws": _os.environ.get("WM_LSTM_BWD_WS", "1") == "1", "fwd_ws": True}
+
+
+def set_lstm_fwd_wave_specialised(on: bool):
+    """LSTM forward (wm_lstm_fwd_fused): 1 (default) the input projection of the next 32-step chunk runs on four helper waves beside the
+    recurrence, 0 inside the recurrence's own waves.  Bit-identical results.  WM_LSTM_FWD_WS=0/1 sets the default."""
+    lib.wm_set_lstm_fwd_wave_specialised(1 if on else 0, None)
+    _LSTM["fwd_ws"] = bool(on)
+
+
+if "WM_LSTM_FWD_WS" in _os.environ:
+    set_lstm_fwd_wave_specialised(_os.environ["WM_LSTM_FWD_WS"] == "1")
 
 
 def set_lstm_bwd_wave_specialised(on: bool):

@@ -189,6 +189,10 @@ int wm_lstm_fwd(const float* xp, const float* w_hh, float* hout, float* gates, f
  * activations / cell states for wm_lstm_bwd, exactly as wm_lstm_fwd writes them.  T >= 8. */
 int wm_lstm_fwd_fused(const float* x, const float* w_ih, const float* b_ih, const float* b_hh, const float* w_hh,
                       float* hout, float* gates, float* cst, int B, int T, wm_stream_t stream);
+/* build of wm_lstm_fwd_fused (process-wide; default 1): 1 wave-specialised -- the recurrence on waves 0..3, the projection of the next
+ * 32-step chunk on four helper waves that share its one barrier per step; 0 the projection inside the recurrence's own waves.
+ * Bit-identical results. */
+int wm_set_lstm_fwd_wave_specialised(int on, wm_stream_t stream);
 int wm_lstm_bwd(float* gates, const float* cst, const float* dh_out, const float* w_hh, int B, int T, wm_stream_t stream);
 int wm_lstm_dx(const float* da, const float* w_ih, float* dx, int B, int T, wm_stream_t stream);
 /* arithmetic of wm_lstm_dx and wm_lstm_wgrad (process-wide): 1 bf16x6 split on the bf16 matrix cores (default,

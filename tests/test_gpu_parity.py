@@ -704,6 +704,37 @@ def test_lstm_bwd_wave_specialised(awm, dev, monkeypatch, B, T):
         assert rel_err(a, b_) < 2e-6, (name, rel_err(a, b_))
 
 
+@pytest.mark.parametrize("B,T", [(2, 64), (1, 100), (3, 1000), (2, 8), (1, 36)])
+def test_lstm_fwd_wave_specialised_is_bit_identical(awm, dev, B, T):
+    """wm_lstm_fwd_fused's two builds -- the projection of the next chunk on four helper waves (default) or inside the recurrence's own
+    waves -- run the same arithmetic in the same order: h, the saved gate activations and cell states must agree bit for bit, on lengths
+    with ragged 32-step chunks and 16-step groups, in training (saving) and inference form."""
+    from awm_amd import ops
+    from awm_amd.ops import _p, _stream, lib
+    g = torch.Generator().manual_seed(55)
+    k = 1.0 / 8.0
+    wi, wh = ((torch.rand(256, 64, generator=g) * 2 - 1) * k).to(dev), ((torch.rand(256, 64, generator=g) * 2 - 1) * k).to(dev)
+    bi, bh = ((torch.rand(256, generator=g) * 2 - 1) * k).to(dev), ((torch.rand(256, generator=g) * 2 - 1) * k).to(dev)
+    x = rnd(B, 64, T, seed=56).to(dev)
+    outs = []
+    try:
+        for ws in (True, False):
+            ops.set_lstm_fwd_wave_specialised(ws)
+            for save in (True, False):
+                h = torch.full((B, 64, T), float("nan"), device=dev)
+                gates = torch.full((B, T, 256), float("nan"), device=dev) if save else None
+                cst = torch.full((B, T, 64), float("nan"), device=dev) if save else None
+                lib.wm_lstm_fwd_fused(_p(x), _p(wi), _p(bi), _p(bh), _p(wh), _p(h), _p(gates), _p(cst), B, T, _stream())
+                outs.append((h, gates, cst))
+    finally:
+        ops.set_lstm_fwd_wave_specialised(True)
+    for a, b_ in ((outs[0], outs[2]), (outs[1], outs[3])):
+        for t_a, t_b in zip(a, b_):
+            if t_a is not None:
+                assert torch.isfinite(t_a).all() and torch.equal(t_a, t_b)
+    assert torch.equal(outs[0][0], outs[1][0])          # saving changes nothing in h
+
+
 def test_lstm_long_horizon(awm, dev):
     """all 16000 dependent steps (SURVEY.md hard part 1): drift must stay inside 1e-4"""
     from awm_amd import ops
