@@ -262,8 +262,11 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __re
 
 // max |x| over a tensor -> the power-of-two scale of the f16 two-piece split kernels: {gs, 1 / gs} with max |x| gs in (2^(L-1), 2^L].
 // Pass 1: one partial per workgroup (streaming, 1024 workgroups); pass 2: one workgroup.
-__global__ __launch_bounds__(256) void absmax_kernel(const float4* __restrict__ x, size_t n4, float* __restrict__ partial) {
+__device__ unsigned g_absmax_ticket = 0;          // arrivals of the current wm_gscale_absmax launch (one launch at a time per device)
+__global__ __launch_bounds__(256) void absmax_kernel(const float4* __restrict__ x, size_t n4, float* __restrict__ partial,
+                                                     float log2_target, float* __restrict__ gscale) {
     __shared__ float red[4];
+    __shared__ unsigned last;
     float m = 0.f;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
         const float4 v = stream_load(x + i);
@@ -273,7 +276,30 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float4* __restrict__ 
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
     __syncthreads();
-    if (threadIdx.x == 0) partial[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    if (threadIdx.x == 0) {
+        partial[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        __threadfence();
+        last = (atomicAdd(&g_absmax_ticket, 1u) == gridDim.x - 1) ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!last) return;
+    // the workgroup that arrives last reduces the partials and writes the scale (no second launch)
+    __threadfence();
+    float mm = 0.f;
+    for (int i = threadIdx.x; i < (int)gridDim.x; i += 256) mm = fmaxf(mm, __builtin_nontemporal_load(partial + i));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mm = fmaxf(mm, __shfl_xor(mm, o));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mm;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        mm = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        float gs = 1.f;
+        if (mm > 0.f && mm < 3.0e38f) gs = exp2f(floorf(log2_target - log2f(mm)));      // NaN / inf / all-zero input: scale 1
+        gs = fminf(fmaxf(gs, 1.0e-30f), 1.0e30f);
+        gscale[0] = gs; gscale[1] = 1.f / gs;
+        g_absmax_ticket = 0;
+    }
 }
 __global__ __launch_bounds__(256) void gscale_from_max_kernel(const float* __restrict__ partial, int n, float log2_target,
                                                               float* __restrict__ gscale) {
@@ -384,10 +410,10 @@ int wm_gscale_from_max(const float* maxes, int n, float log2_target, float* gsca
 int wm_gscale_absmax(const float* x, long long n, float* scratch, float log2_target, float* gscale, hipStream_t stream) {
     if (n <= 0 || (n & 3)) return (int)hipErrorInvalidValue;
     const size_t n4 = (size_t)n / 4;
-    const int grid = (int)((n4 + 255) / 256 < 1024 ? (n4 + 255) / 256 : 1024);
-    hipLaunchKernelGGL(absmax_kernel, dim3(grid), dim3(256), 0, stream, reinterpret_cast<const float4*>(x), n4, scratch);
-    WM_CHECK_LAUNCH();
-    hipLaunchKernelGGL(gscale_from_max_kernel, dim3(1), dim3(256), 0, stream, (const float*)scratch, grid, log2_target, gscale);
+    // eight float4 per thread and workgroup at least: a small tensor (a weight matrix) is a handful of workgroups, not a thousand
+    const size_t want = (n4 + 2047) / 2048;
+    const int grid = (int)(want < 1 ? 1 : (want < 1024 ? want : 1024));
+    hipLaunchKernelGGL(absmax_kernel, dim3(grid), dim3(256), 0, stream, reinterpret_cast<const float4*>(x), n4, scratch, log2_target, gscale);
     WM_CHECK_LAUNCH();
     return 0;
 }

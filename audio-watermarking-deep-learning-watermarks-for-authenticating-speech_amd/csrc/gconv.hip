@@ -334,6 +334,291 @@ int launch_gconv2(GConvArgs a, hipStream_t stream) {
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The same implicit GEMM on the f16 matrix cores with the f16 two-piece split (hi = f16(v s), lo = f16(v s - hi); three products
+// lo hi, hi lo, hi hi per product, fp32 accumulate: fp32-grade) for layers whose input channel count is a multiple
+// of 16 -- v_mfma_f32_32x32x16_f16 contracts 16 (channel, tap) pairs per instruction where v_mfma_f32_32x32x2_f32 contracts 2 at half
+// the rate, so the wide layers gain most.  The K dimension is walked as (16-channel chunk, tap):
+//   * weights: a pre-packed f16 image [chunk][tap][Mtot][16 channels] x {hi, lo} (wm_gconv_pack_h: w * ws, ws a power of two from
+//     max |w|, {ws, 1 / ws} behind the image).  An A fragment (one output row, 8 consecutive channels) is ONE 16-byte global load,
+//     coalesced over the wave's 32 rows: the weights never pass through LDS (L2 / L1 serve the re-use between tiles and waves).
+//   * input: a chunk's [16][XW] window is staged global -> registers -> LDS as a channel-minor image [position][16 channels] x {hi, lo}
+//     (pitch 24 halves), one chunk ahead of the matrix phase; a B fragment (one output position, 8 consecutive channels at one tap) is
+//     one aligned ds_read_b128 at row position * S + tap.  gscale (data gradients): the input is multiplied by gs before the split
+//     and clamped to the f16 range; the accumulators leave times 1 / (ws gs).
+// Epilogue as gconv2_kernel's.
+// ---------------------------------------------------------------------------------------------------------------
+typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+struct GConvHArgs {
+    GConvArgs g;
+    const unsigned short* wph;      // [2 pieces][Cin / 16][K][Mtot][16] f16, then {ws, 1 / ws}
+    const float* gscale;            // {gs, 1 / gs} or null
+};
+
+template <int MW, int WM, int WN, int XRH>   // XRH: staged window elements (channel pairs) per thread, 8 XW <= 256 XRH
+__global__ __launch_bounds__(256) void gconvh_kernel(GConvHArgs ha) {
+    const GConvArgs& a = ha.g;
+    constexpr int NWN = 4 / MW, BM = MW * WM * 32, BN = NWN * WN * 32, PX = 24;
+    extern __shared__ __align__(16) unsigned char smem_h[];
+    unsigned short* Xs = reinterpret_cast<unsigned short*>(smem_h);      // [2 buffers][2 pieces][XWP][PX]
+    const int K = a.K, S = a.S, XW = a.XW;
+    const int XWP = XW + 8;                                                 // slack rows: discarded columns read past the window
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), half = lane >> 5, l31 = lane & 31;
+    const int wm_ = wave % MW, wn = wave / MW;
+    const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM, nb = blockIdx.z;
+    const int u0 = n0 * S - a.P;
+    const int nchunks = a.Cin >> 4;
+    const size_t piece = (size_t)nchunks * K * a.Mtot * 16;                 // halves per weight piece
+    const float* tail = reinterpret_cast<const float*>(ha.wph + 2 * piece);
+    const float gs = ha.gscale ? ha.gscale[0] : 1.f;
+    const float dinv = tail[1] * (ha.gscale ? ha.gscale[1] : 1.f);
+
+    // ---- staging map: element i of a thread = (channel pair cp, window position j): idx = tid + 256 i = cp * XW + j
+    const int nx = (8 * XW + 255) >> 8;
+    unsigned xo[XRH];            // byte offset of channel 2 cp at the clamped position
+    unsigned xl[XRH];            // LDS dword index (position * PX / 2 + cp), 0xffffffff: nothing to write
+    unsigned xz = 0;             // bit i: zero padding
+#pragma unroll
+    for (int i = 0; i < XRH; ++i) {
+        const int idx = tid + 256 * i, cp = idx / XW, j = idx - cp * XW, u = u0 + j;
+        const bool live = (i < nx) && (cp < 8);
+        xz |= ((u < 0 || u >= a.Lin) ? 1u : 0u) << i;
+        xo[i] = (unsigned)((2 * min(cp, 7)) * a.Lin + min(max(u, 0), a.Lin - 1)) * 4u;
+        xl[i] = live ? (unsigned)(j * (PX / 2) + cp) : 0xffffffffu;
+    }
+    const int cin1 = a.x2 ? a.Cin1 : a.Cin;
+    const wm_srd_t sx = make_srd(a.x + (size_t)nb * cin1 * a.Lin, (size_t)cin1 * a.Lin * sizeof(float));
+    const wm_srd_t sx2 = make_srd(a.x2 ? a.x2 + (size_t)nb * (a.Cin - cin1) * a.Lin : a.x, (size_t)(a.Cin - cin1) * a.Lin * sizeof(float));
+    const wm_srd_t sw = make_srd(reinterpret_cast<const float*>(ha.wph), 2 * piece * sizeof(unsigned short));
+    float xa[XRH], xb[XRH];
+    auto load_chunk = [&](int c) {
+        const int c0 = 16 * c;
+        const bool second = c0 >= cin1;
+        const wm_srd_t sxc = second ? sx2 : sx;
+        const unsigned s0 = (unsigned)((c0 - (second ? cin1 : 0)) * a.Lin) * 4u;
+#pragma unroll
+        for (int i = 0; i < XRH; ++i)
+            if (i < nx) { xa[i] = buf_load(sxc, xo[i], s0); xb[i] = buf_load(sxc, xo[i] + (unsigned)a.Lin * 4u, s0); }
+    };
+    auto store_chunk = [&](unsigned short* buf) {
+        unsigned* hi32 = reinterpret_cast<unsigned*>(buf);
+        unsigned* lo32 = reinterpret_cast<unsigned*>(buf + XWP * PX);
+#pragma unroll
+        for (int i = 0; i < XRH; ++i) {
+            if (i < nx) {
+                const bool z = (xz >> i) & 1u;
+                const float va = z ? 0.f : __builtin_amdgcn_fmed3f(xa[i] * gs, -6.0e4f, 6.0e4f);
+                const float vb = z ? 0.f : __builtin_amdgcn_fmed3f(xb[i] * gs, -6.0e4f, 6.0e4f);
+                const h16x2 h_ = __builtin_convertvector(f32x2{va, vb}, h16x2);
+                const h16x2 l_ = __builtin_convertvector(f32x2{va - (float)h_.x, vb - (float)h_.y}, h16x2);
+                if (xl[i] != 0xffffffffu) { hi32[xl[i]] = __builtin_bit_cast(unsigned, h_); lo32[xl[i]] = __builtin_bit_cast(unsigned, l_); }
+            }
+        }
+    };
+    const int bufh = 2 * XWP * PX;                                          // halves per buffer (two pieces)
+    // the slack rows are read by discarded columns only: keep them finite
+    for (int i = tid; i < 2 * 2 * 8 * PX / 2; i += 256) {
+        const int bq = i / (8 * PX / 2), r = i - bq * (8 * PX / 2);          // bq = buffer * 2 + piece
+        reinterpret_cast<unsigned*>(Xs + (bq >> 1) * bufh + (bq & 1) * XWP * PX + XW * PX)[r] = 0u;
+    }
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    // weight fragment of (chunk c, tap, row tile i, piece p): 16 bytes at ((c K + tap) Mtot + row) * 16 + 8 half halves; rows past Mtot read 0
+    unsigned wrow[WM], wrow_lo[WM];
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+        const int m = m0 + (wm_ * WM + i) * 32 + l31;
+        wrow[i] = (m < a.Mtot) ? (unsigned)(m * 16 + 8 * half) * 2u : 0xfffffff0u;
+        wrow_lo[i] = (m < a.Mtot) ? wrow[i] + (unsigned)(piece * 2) : 0xfffffff0u;
+    }
+    auto load_w = [&](int c, int tap, u32x4 (&A)[WM][2]) {
+        const unsigned s0 = (unsigned)(((size_t)(c * K + tap) * a.Mtot) * 16) * 2u;
+#pragma unroll
+        for (int i = 0; i < WM; ++i) {
+            A[i][0] = __builtin_bit_cast(u32x4, buf_load4(sw, wrow[i], s0));
+            A[i][1] = __builtin_bit_cast(u32x4, buf_load4(sw, wrow_lo[i], s0));
+        }
+    };
+    auto mma = [&](const u32x4& A_, const u32x4& B_, f32x16 c) -> f32x16 {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, A_), __builtin_bit_cast(h16x8, B_), c, 0, 0, 0);
+    };
+    load_chunk(0);
+    store_chunk(Xs);
+    __syncthreads();
+    // weight fragments of this k-step and of the next two (in flight): an L2 hit takes longer than the 6-12 MFMAs of one k-step
+    u32x4 Ac[WM][2], An[WM][2], An2[WM][2];
+    const int nq = nchunks * K;                                             // k-steps q = c K + tap
+    auto load_q = [&](int q, u32x4 (&A)[WM][2]) {
+        if (q < nq) { const int c_ = q / K; load_w(c_, q - c_ * K, A); }
+    };
+    load_q(0, Ac); load_q(1, An);
+    for (int c = 0; c < nchunks; ++c) {
+        const unsigned short* cur = Xs + (c & 1) * bufh;
+        if (c + 1 < nchunks) load_chunk(c + 1);
+        const unsigned short* xrow = cur + ((wn * (WN * 32) + l31) * S) * PX + 8 * half;
+        u32x4 Bh[WN], Bl[WN], Bhn[WN], Bln[WN];          // this tap's input fragments, the next tap's (LDS reads in flight)
+        auto load_b = [&](int tap, u32x4 (&H_)[WN], u32x4 (&L_)[WN]) {
+#pragma unroll
+            for (int j = 0; j < WN; ++j) {
+                const unsigned short* pB = xrow + (j * 32 * S + tap) * PX;
+                H_[j] = *reinterpret_cast<const u32x4*>(pB);
+                L_[j] = *reinterpret_cast<const u32x4*>(pB + XWP * PX);
+            }
+        };
+        load_b(0, Bh, Bl);
+        for (int tap = 0; tap < K; ++tap) {
+            load_q(c * K + tap + 2, An2);
+            if (tap + 1 < K) load_b(tap + 1, Bhn, Bln);
+            // piece products outermost: the WM x WN accumulators form independent chains between two dependent MFMAs
+#pragma unroll
+            for (int pp = 0; pp < 3; ++pp)
+#pragma unroll
+                for (int i = 0; i < WM; ++i)
+#pragma unroll
+                    for (int j = 0; j < WN; ++j)
+                        acc[i][j] = mma(Ac[i][pp == 0 ? 1 : 0], pp == 1 ? Bl[j] : Bh[j], acc[i][j]);     // lo hi, hi lo, hi hi
+#pragma unroll
+            for (int i = 0; i < WM; ++i) { Ac[i][0] = An[i][0]; Ac[i][1] = An[i][1]; An[i][0] = An2[i][0]; An[i][1] = An2[i][1]; }
+#pragma unroll
+            for (int j = 0; j < WN; ++j) { Bh[j] = Bhn[j]; Bl[j] = Bln[j]; }
+        }
+        if (c + 1 < nchunks) store_chunk(Xs + ((c + 1) & 1) * bufh);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] *= dinv;
+
+    // ---- epilogue (gconv2_kernel's): + bias + per-clip vector + residual, ELU / ELU', (pixel-shuffled) store
+    const size_t clip = (size_t)nb * a.Cout * a.Lout;
+    const wm_srd_t sy = make_srd(a.y + clip, (size_t)a.Cout * a.Lout * sizeof(float));
+    const wm_srd_t sr = make_srd(a.res ? a.res + clip : a.y + clip, (size_t)a.Cout * a.Lout * sizeof(float));
+    const bool has_res = a.res != nullptr && a.act != 2, act = a.act == 1, mul_dact = a.act == 2 && a.res != nullptr;
+    const float* vecb = a.vec ? a.vec + (size_t)nb * a.Cout : nullptr;
+    const unsigned inv = (65536u + (unsigned)a.nph - 1u) / (unsigned)a.nph;
+    const bool shuffle = a.st > 1;
+    int ncol[WN];
+#pragma unroll
+    for (int j = 0; j < WN; ++j) ncol[j] = n0 + (wn * WN + j) * 32 + l31;
+    const int tlo = n0 * a.st - a.shp, thi = (n0 + BN - 1) * a.st + a.st - 1 - a.shp;
+    const bool inner = (m0 + BM <= a.Mtot) && (n0 + BN <= a.Nout) && (!shuffle || (tlo >= 0 && thi < a.Lout));
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+#pragma unroll
+        for (int rh = 0; rh < 16; rh += 8) {
+            unsigned off[8][WN];
+#pragma unroll
+            for (int r8 = 0; r8 < 8; ++r8) {
+                const int r = rh + r8;
+                const int m = m0 + (wm_ * WM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int mc = min(m, a.Mtot - 1);
+                int co = mc, ph = 0;
+                if (shuffle) { co = (int)(((unsigned)mc * inv) >> 16); ph = mc - co * a.nph; }
+                float add = a.bias ? a.bias[co] : 0.f;
+                if (vecb) add += vecb[co];
+                const int rowv = co * a.Lout + ph - (shuffle ? a.shp : 0);
+#pragma unroll
+                for (int j = 0; j < WN; ++j) {
+                    const int t = shuffle ? ncol[j] * a.st + ph - a.shp : ncol[j];
+                    const bool ok = inner || (m < a.Mtot && ncol[j] < a.Nout && t >= 0 && t < a.Lout);
+                    off[r8][j] = ok ? (unsigned)(rowv + (shuffle ? ncol[j] * a.st : ncol[j])) * 4u : 0xffffffffu;
+                    acc[i][j][r] += add;
+                }
+            }
+            if (has_res) {
+                float rv[8][WN];
+#pragma unroll
+                for (int r8 = 0; r8 < 8; ++r8)
+#pragma unroll
+                    for (int j = 0; j < WN; ++j) rv[r8][j] = buf_load(sr, off[r8][j], 0u);
+#pragma unroll
+                for (int r8 = 0; r8 < 8; ++r8)
+#pragma unroll
+                    for (int j = 0; j < WN; ++j) acc[i][j][rh + r8] += rv[r8][j];
+            }
+            if (act) {
+#pragma unroll
+                for (int r8 = 0; r8 < 8; ++r8)
+#pragma unroll
+                    for (int j = 0; j < WN; ++j) acc[i][j][rh + r8] = elu1(acc[i][j][rh + r8]);
+            }
+            if (mul_dact) {
+                float yv[8][WN];
+#pragma unroll
+                for (int r8 = 0; r8 < 8; ++r8)
+#pragma unroll
+                    for (int j = 0; j < WN; ++j) yv[r8][j] = buf_load(sr, off[r8][j], 0u);
+#pragma unroll
+                for (int r8 = 0; r8 < 8; ++r8)
+#pragma unroll
+                    for (int j = 0; j < WN; ++j) acc[i][j][rh + r8] *= (yv[r8][j] > 0.f ? 1.f : yv[r8][j] + 1.f);
+            }
+#pragma unroll
+            for (int r8 = 0; r8 < 8; ++r8)
+#pragma unroll
+                for (int j = 0; j < WN; ++j) buf_store(sy, acc[i][j][rh + r8], off[r8][j], 0u);
+        }
+    }
+}
+
+template <int MW, int WM, int WN, int XRH>
+int launch_gconvh_x(GConvHArgs ha, hipStream_t stream) {
+    GConvArgs& a = ha.g;
+    constexpr int BM = MW * WM * 32, BN = (4 / MW) * WN * 32;
+    a.XW = (BN - 1) * a.S + a.K;
+    if (8 * a.XW > 256 * XRH) return (int)hipErrorInvalidValue;         // staged window elements per thread <= XRH
+    const size_t lds = (size_t)2 * 2 * (a.XW + 8) * 24 * sizeof(unsigned short);
+    if (lds > 160 * 1024) return (int)hipErrorInvalidValue;
+    auto kern = gconvh_kernel<MW, WM, WN, XRH>;
+    static wm::DevOnce once;
+    if (!wm::dev_done(once)) {
+        WM_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        wm::dev_mark(once);
+    }
+    dim3 grid((a.Nout + BN - 1) / BN, (a.Mtot + BM - 1) / BM, a.NB);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, ha);
+    WM_CHECK_LAUNCH();
+    return 0;
+}
+template <int MW, int WM, int WN>
+int launch_gconvh(GConvHArgs ha, hipStream_t stream) {
+    constexpr int BN = (4 / MW) * WN * 32;
+    const int XW = (BN - 1) * ha.g.S + ha.g.K;
+    if (8 * XW <= 256 * 6) return launch_gconvh_x<MW, WM, WN, 6>(ha, stream);     // stride-1 layers: a short window, 56 registers less
+    return launch_gconvh_x<MW, WM, WN, 20>(ha, stream);
+}
+
+// f16 two-piece image of a wm_gconv weight matrix wp [Cin * K][Mtot] (row ci * K + tap): out[piece][ci / 16][tap][m][ci % 16];
+// the scale {ws, 1 / ws} sits behind the image (written by gscale_from_max beforehand)
+__global__ __launch_bounds__(256) void gconv_pack_h_kernel(const float* __restrict__ wp, unsigned short* __restrict__ out, int Cin, int K, int Mtot) {
+    const size_t n = (size_t)Cin * K * Mtot, piece = n;
+    const float ws = reinterpret_cast<const float*>(out + 2 * piece)[0];
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        // i walks the OUTPUT image: ((c K + tap) Mtot + m) * 16 + e
+        const int e = (int)(i & 15);
+        const size_t q = i >> 4;
+        const int m = (int)(q % Mtot);
+        const size_t ct = q / Mtot;
+        const int tap = (int)(ct % K), c = (int)(ct / K);
+        const float v = wp[((size_t)(16 * c + e) * K + tap) * Mtot + m] * ws;
+        const _Float16 hi = (_Float16)v;
+        const _Float16 lo = (_Float16)(v - (float)hi);
+        out[i] = __builtin_bit_cast(unsigned short, hi);
+        out[piece + i] = __builtin_bit_cast(unsigned short, lo);
+    }
+}
+
 // [A][C][L] -> [L][C][A]   (batch-major <-> time-major sequence layouts around the LSTM)
 __global__ void permute_acl_kernel(const float* __restrict__ x, float* __restrict__ y, int A, int C, int L) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -916,6 +1201,8 @@ __global__ __launch_bounds__(256) void lstm_seq_bwd_kernel(float* gates, const f
 
 extern "C" {
 
+int wm_gscale_absmax(const float* x, long long n, float* scratch, float log2_target, float* gscale, hipStream_t stream);   // bn.hip
+
 // y[nb][co][t'] = act( bias[co] + vec[nb][co] + res + sum_{ci,k} wp[ci*K+k][m] * x[nb][ci][n*S + k - P] )
 //   st == 1: m = co, t' = n (Cout == Mtot, Lout == Nout);  st > 1: m = co*st + phase, t' = n*st + phase - shp.
 int wm_gconv(const float* x, const float* wp, const float* bias, const float* vec, const float* res, float* y, int NB,
@@ -940,6 +1227,43 @@ int wm_gconv(const float* x, const float* wp, const float* bias, const float* ve
     else rc = launch_gconv2<1, 1, 2, true>(a, stream);
     if (rc == (int)hipErrorInvalidValue) rc = launch_gconv2<2, 1, 1, true>(a, stream);   // widest-stride shapes: the narrowest input tile
     return rc;
+}
+
+// wm_gconv on the f16 two-piece split: wph = wm_gconv_pack_h's image of the SAME wp; Cin % 16 == 0 (and Cin1 % 16 == 0 with two sources);
+// gscale = {gs, 1 / gs} for a gradient input (wm_gscale_absmax), NULL for activations.  hipErrorInvalidValue when the shape is outside
+// the kernel's window limits (the caller then uses wm_gconv).
+int wm_gconv_h(const float* x, const void* wph, const float* bias, const float* vec, const float* res, float* y, int NB,
+               int Cin, int Lin, int K, int S, int P, int Mtot, int Nout, int st, int shp, int Cout, int Lout, int act,
+               const float* x2, int Cin1, int nph, const float* gscale, hipStream_t stream) {
+    if (NB <= 0 || Cin <= 0 || (Cin & 15) || K <= 0 || K > 16 || S <= 0 || S > 8 || Mtot <= 0 || Nout <= 0 || st < 1 || st > 8 || Lin <= 0 ||
+        Lin >= (1 << 24) || NB > 65535 || Mtot >= 8192 || !wph)
+        return (int)hipErrorInvalidValue;
+    if (nph <= 0) nph = st;
+    if (nph > st || (x2 && (Cin1 <= 0 || Cin1 >= Cin || (Cin1 & 15)))) return (int)hipErrorInvalidValue;
+    GConvHArgs ha{GConvArgs{x, nullptr, bias, vec, res, y, NB, Cin, Lin, K, S, P, Mtot, Nout, st, shp, Cout, Lout, act, 0, 0, x2,
+                            x2 ? Cin1 : Cin, nph},
+                  reinterpret_cast<const unsigned short*>(wph), gscale};
+    int rc;
+    if (Nout <= 64) rc = Mtot > 64 ? launch_gconvh<2, 2, 1>(ha, stream) : launch_gconvh<2, 1, 1>(ha, stream);
+    else if (Mtot > 64) rc = launch_gconvh<2, 2, 2>(ha, stream);
+    else if (Mtot > 32) rc = launch_gconvh<2, 1, 2>(ha, stream);
+    else rc = launch_gconvh<1, 1, 2>(ha, stream);
+    if (rc == (int)hipErrorInvalidValue && Nout > 64) rc = Mtot > 64 ? launch_gconvh<2, 2, 1>(ha, stream) : launch_gconvh<2, 1, 1>(ha, stream);
+    return rc;
+}
+
+// f16 image of wp [Cin * K][Mtot] for wm_gconv_h: wph holds 2 * Cin * K * Mtot f16 + 2 floats; scratch >= 1024 floats
+int wm_gconv_pack_h(const float* wp, void* wph, float* scratch, int Cin, int K, int Mtot, hipStream_t stream) {
+    if (!wp || !wph || !scratch || Cin <= 0 || (Cin & 15) || K <= 0 || Mtot <= 0) return (int)hipErrorInvalidValue;
+    const long long n = (long long)Cin * K * Mtot;
+    unsigned short* out = reinterpret_cast<unsigned short*>(wph);
+    float* tail = reinterpret_cast<float*>(out + 2 * n);
+    int rc = wm_gscale_absmax(wp, n, scratch, 10.0f, tail, stream);       // max |w| ws in (2^9, 2^10]
+    if (rc) return rc;
+    const int grid = (int)((n + 255) / 256 < 512 ? (n + 255) / 256 : 512);
+    hipLaunchKernelGGL(gconv_pack_h_kernel, dim3(grid), dim3(256), 0, stream, wp, out, Cin, K, Mtot);
+    WM_CHECK_LAUNCH();
+    return 0;
 }
 
 int wm_permute_acl(const float* x, float* y, int A, int C, int L, hipStream_t stream) {

@@ -26,10 +26,33 @@ STRIDES = [2, 4, 5, 8]                                          # :47
 
 
 # ------------------------------------------------------------------------------------------ raw launches
-def _gconv_raw(x, wp, bias, K, S, P, Mtot, Nout, st, shp, Cout, Lout, act=0, res=None, vec=None, x2=None, nph=0, out=None):
+import os as _os0
+_GCONV = {"f16x3": _os0.environ.get("WM_GCONV_F16X3", "1") == "1"}
+
+
+def set_gconv_f16x3(on: bool):
+    """generic convolution family (wm_gconv: forward, transposed, data gradients) for layers with Cin % 16 == 0: 1 (default) the f16
+    two-piece split on the f16 matrix cores (wm_gconv_h; weights scaled from max |w|, a gradient input from max |g|), 0 native fp32
+    MFMA.  WM_GCONV_F16X3=0/1 sets the default."""
+    _GCONV["f16x3"] = bool(on)
+
+
+def _gconv_raw(x, wp, bias, K, S, P, Mtot, Nout, st, shp, Cout, Lout, act=0, res=None, vec=None, x2=None, nph=0, out=None, grad_in=False):
     NB, Cin, Lin = x.shape
     y = _f32(NB, Cout, Lout, device=x.device) if out is None else out
     Cin_tot = Cin + (x2.shape[1] if x2 is not None else 0)
+    if _GCONV["f16x3"] and Cin % 16 == 0 and Cin_tot % 16 == 0 and ops.conv_bf16x6():
+        wph = torch.empty(2 * Cin_tot * K * Mtot + 4, dtype=torch.int16, device=x.device)
+        lib.wm_gconv_pack_h(_p(wp), _p(wph), _p(_f32(1024, device=x.device)), Cin_tot, K, Mtot, _stream())
+        gsc = None
+        if grad_in:
+            gsc = ops.gscale_absmax(x)
+            if x2 is not None:                       # one scale for both gradient sources: the smaller of the two
+                g2 = ops.gscale_absmax(x2)
+                gsc = torch.stack([torch.minimum(gsc[0], g2[0]), torch.maximum(gsc[1], g2[1])])
+        lib.wm_gconv_h(_p(x), _p(wph), _p(bias), _p(vec), _p(res), _p(y), NB, Cin_tot, Lin, K, S, P, Mtot, Nout, st, shp, Cout, Lout, act,
+                       _p(x2), Cin if x2 is not None else 0, nph, _p(gsc), _stream())
+        return y
     lib.wm_gconv(_p(x), _p(wp), _p(bias), _p(vec), _p(res), _p(y), NB, Cin_tot, Lin, K, S, P, Mtot, Nout, st, shp, Cout, Lout, act,
                  _p(x2), Cin if x2 is not None else 0, nph, _stream())
     return y
@@ -70,7 +93,7 @@ def _conv_dgrad(g, w, stride, padding, Lin, res=None, act=0, out=None):
         return _c64_conv(g, w, 1, None, res, 7 if act == 2 else (2 if res is not None else 3))
     if stride == 1:
         wp = w.flip(2).permute(0, 2, 1).reshape(Cout * K, Cin).contiguous()             # rows (co, kk): W[co][ci][K-1-kk]
-        return _gconv_raw(g, wp, None, K, 1, K - 1 - padding, Cin, Lin, 1, 0, Cin, Lin, act, res, None, None, 0, out)
+        return _gconv_raw(g, wp, None, K, 1, K - 1 - padding, Cin, Lin, 1, 0, Cin, Lin, act, res, None, None, 0, out, grad_in=True)
     # strided conv: its data gradient is a transposed conv = Kg-tap conv onto Cin*stride phase rows + pixel shuffle
     Kg = (K + stride - 1) // stride
     wz = torch.zeros(Cout, Cin, Kg * stride, dtype=w.dtype, device=w.device)
@@ -78,7 +101,7 @@ def _conv_dgrad(g, w, stride, padding, Lin, res=None, act=0, out=None):
     # wp[(co*Kg + kk)][ci*stride + phase] = W[co][ci][phase + (Kg-1-kk)*stride]
     wp = wz.reshape(Cout, Cin, Kg, stride).flip(2).permute(0, 2, 1, 3).reshape(Cout * Kg, Cin * stride).contiguous()
     Nout = (Lin - 1 + padding) // stride + 1
-    return _gconv_raw(g, wp, None, Kg, 1, Kg - 1, Cin * stride, Nout, stride, padding, Cin, Lin, act, res)
+    return _gconv_raw(g, wp, None, Kg, 1, Kg - 1, Cin * stride, Nout, stride, padding, Cin, Lin, act, res, grad_in=True)
 
 
 def _strided_block_dgrad(gz1, w1, gz2, ws, stride, Lin):
@@ -93,7 +116,7 @@ def _strided_block_dgrad(gz1, w1, gz2, ws, stride, Lin):
     wp = wcat.reshape(2 * Cout, Cin * K).contiguous()                           # [(src, co)][ci*K + k]
     NB, Lo = gz1.shape[0], gz1.shape[2]
     dx = torch.zeros(NB, Cin, Lin, dtype=torch.float32, device=gz1.device)      # positions no tap reaches stay zero
-    return _gconv_raw(gz1, wp, None, 1, 1, 0, Cin * K, Lo, stride, 1, Cin, Lin, 0, None, None, gz2, K, dx)
+    return _gconv_raw(gz1, wp, None, 1, 1, 0, Cin * K, Lo, stride, 1, Cin, Lin, 0, None, None, gz2, K, dx, grad_in=True)
 
 
 import os as _os
@@ -215,7 +238,7 @@ class ConvTFn(torch.autograd.Function):
         Cin, Cout, K = w.shape
         # dx[ci][j] = sum_{co,k} g[co][j*st - pad + k] W[ci][co][k]: a strided conv over g
         wp = w.permute(1, 2, 0).reshape(Cout * K, Cin).contiguous()
-        dx = _gconv_raw(g, wp, None, K, st, pad, Cin, x.shape[2], 1, 0, Cin, x.shape[2])
+        dx = _gconv_raw(g, wp, None, K, st, pad, Cin, x.shape[2], 1, 0, Cin, x.shape[2], grad_in=True)
         # dW[ci][co][q*st + ph] = sum_t x[ci][t] * g'[co*st + ph][t + q] with the stride phases of g as channels:
         # a K = 2 stride-1 GEMM over Cout*st channels
         gp = _gather_taps(g, st, st, pad, x.shape[2] + 1, 1)
@@ -295,7 +318,7 @@ class LSTMLayerFn(ops.GradAwareFunction):
         dc = _f32(H, B, device=dev)
         lib.wm_lstm_seq_bwd(_p(gates), _p(cs), _p(dout), _p(w_hh.t().contiguous()), _p(dc), T, H, B, st)   # gates -> da
         da = gates                                   # [T][4H][B]
-        dx = _gconv_raw(da, w_ih.contiguous(), None, 1, 1, 0, H, B, 1, 0, H, B) if ctx.needs_input_grad[0] else None
+        dx = _gconv_raw(da, w_ih.contiguous(), None, 1, 1, 0, H, B, 1, 0, H, B, grad_in=True) if ctx.needs_input_grad[0] else None
         dwi, db = _gwgrad_raw(da, seq, H, B, 0, (4 * H, H, 1), 1, 0, True)
         dwh, _ = _gwgrad_raw(da, hs[:T], H, B, 0, (4 * H, H, 1), 1, 0, False)
         return dx, dwi.reshape(4 * H, H), dwh.reshape(4 * H, H), db, db.clone()

@@ -258,6 +258,16 @@ int wm_adam_step(float* p, const float* g, float* m, float* v, long long n, doub
 int wm_gconv(const float* x, const float* wp, const float* bias, const float* vec, const float* res, float* y, int NB,
              int Cin, int Lin, int K, int S, int P, int Mtot, int Nout, int st, int shp, int Cout, int Lout, int act,
              const float* x2, int Cin1, int nph, wm_stream_t stream);
+/* wm_gconv on the f16 two-piece split (three f16 piece products per product on v_mfma_f32_32x32x16_f16, fp32 accumulate, fp32-grade):
+ * same arguments with wph = wm_gconv_pack_h's image of the SAME wp instead of wp; needs Cin % 16 == 0 (and Cin1 % 16 == 0 with a second
+ * source).  gscale = {gs, 1 / gs} (wm_gscale_absmax) when x is a gradient -- it is multiplied by gs before the split and clamped to
+ * +-6e4 --, NULL for activations (split unscaled). */
+int wm_gconv_h(const float* x, const void* wph, const float* bias, const float* vec, const float* res, float* y, int NB,
+               int Cin, int Lin, int K, int S, int P, int Mtot, int Nout, int st, int shp, int Cout, int Lout, int act,
+               const float* x2, int Cin1, int nph, const float* gscale, wm_stream_t stream);
+/* wph: 2 * Cin * K * Mtot f16 ([piece][Cin / 16][K][Mtot][16]: w * ws, ws = the power of two with max |w| ws in (2^9, 2^10]) followed by
+ * {ws, 1 / ws} as two floats; scratch >= 1024 floats */
+int wm_gconv_pack_h(const float* wp, void* wph, float* scratch, int Cin, int K, int Mtot, wm_stream_t stream);
 /* generic weight gradient, one stride-1 GEMM with the taps folded into the column index (deterministic: split-K partial
  * tiles in `slab`, then a fixed-order fp64 reduce -- no float atomics):
  *   G[a][b][k] (+)= sum_{nb,t} A[nb][a][t] * Bx[nb][b][t + k - P],  dbias[a] (+)= sum A   (Conv1d stride 1: A = dL/dy,

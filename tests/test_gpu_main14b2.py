@@ -74,6 +74,42 @@ def test_gconvT_matches_conv_transpose1d(M, cin, cout, st, L):
     assert rel(y, ref) <= TOL
 
 
+@pytest.mark.parametrize("cin,cout,k,stride,pad,L", [(128, 128, 3, 1, 1, 2001), (256, 256, 3, 1, 1, 400), (64, 128, 3, 4, 1, 2001),
+                                                     (32, 64, 3, 2, 1, 1000), (512, 256, 1, 1, 0, 50), (256, 128, 7, 1, 3, 50),
+                                                     (128, 256, 1, 5, 0, 2001), (16, 8, 3, 1, 1, 4000)])
+@pytest.mark.parametrize("gscale", [1.0, 1e-8, 3e3])
+def test_gconv_f16_split_is_fp32_grade(M, cin, cout, k, stride, pad, L, gscale):
+    """the generic convolution on the f16 two-piece split (wm_gconv_h: three products per product; weight image scaled from max |w| by
+    wm_gconv_pack_h, a gradient input from max |g| by wm_gscale_absmax) beside the native fp32-MFMA build (wm_gconv) on the same inputs,
+    both against fp64: forward with ELU, and the data gradient for upstream gradient magnitudes 1e-8 ... 3e3 (strided layers take the
+    transposed / pixel-shuffled route).  Error relative to the result's max below 1e-6 and within 3x of the fp32 build's + 2e-7."""
+    dev = torch.device("cuda:0")
+    x, w, b = rnd(2, cin, L, seed=11), rnd(cout, cin, k, seed=12, scale=0.1), rnd(cout, seed=13)
+    Lout = (L + 2 * pad - k) // stride + 1
+    g = rnd(2, cout, Lout, seed=14) * gscale
+    xr, wr = x.double().requires_grad_(), w.double()
+    yr = F.elu(F.conv1d(xr, wr, b.double(), stride=stride, padding=pad))
+    zr = F.conv1d(xr, wr, b.double(), stride=stride, padding=pad)
+    (dxr,) = torch.autograd.grad(zr, xr, g.double())
+    outs = []
+    try:
+        for h in (False, True):
+            M.set_gconv_f16x3(h)
+            with torch.no_grad():
+                y = M._gconv(x.to(dev), w.to(dev), b.to(dev), stride, pad, act=1) if gscale == 1.0 else None
+                dx = M._conv_dgrad(g.to(dev), w.to(dev), stride, pad, L)
+            outs.append((y, dx))
+    finally:
+        M.set_gconv_f16x3(True)
+    for name, a, h_, r in (("y", outs[0][0], outs[1][0], yr), ("dx", outs[0][1], outs[1][1], dxr)):
+        if a is None:
+            continue
+        e_n, e_h = rel(a, r.detach().float()), rel(h_, r.detach().float())
+        e_n, e_h = float((a.double().cpu() - r.detach()).abs().max() / r.detach().abs().max()), float((h_.double().cpu() - r.detach()).abs().max() / r.detach().abs().max())
+        print(f"{cin}>{cout} k{k} s{stride} g x {gscale:g} {name}: fp32 mfma {e_n:.2e} f16 split {e_h:.2e}")
+        assert e_h < 1e-6 and e_h < 3 * e_n + 2e-7, (name, e_n, e_h)
+
+
 @pytest.mark.parametrize("hd", [256, 32])
 def test_main14b2_forward_golden(M, g2, hd):
     dev = torch.device("cuda:0")
