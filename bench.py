@@ -259,13 +259,30 @@ def kernel_timers(lib, model, mode, bf_mode, batch):
     if model == "main14b_2":
         # wm_gconv args: x wp bias vec res y NB Cin Lin K S P Mtot Nout st shp Cout Lout act stream; > 64 output rows and
         # positions with 16-byte-aligned weight rows = the 128 x 128-tile build
-        return [dict(timer=LaunchTimer(lib, "wm_gconv", lambda a: a[12] > 64 and a[13] > 64 and a[12] % 4 == 0,
-                                       lambda a: (2.0 * a[6] * a[7] * a[9] * a[12] * a[13], 4.0 * a[6] * (a[7] * a[8] + a[16] * a[17]))),
-                     kernel="gconv2_kernel<2,2,2> (wm_gconv, 128 x 128 output tiles: implicit-GEMM Conv1d / ConvTranspose1d / data "
-                            "gradients of the wide main14b_2 layers on the fp32 matrix cores; achieved = sum of algorithmic FLOPs / "
-                            "sum of launch times)",
-                     peak=PEAK_FP32_MFMA_TFLOPS, note=FP32_NOTE, pmc=PMC_MAIN14B2 if batch == 128 else None,
-                     pmc_prefixes=("gconv2_kernel<2, 2, 2",))]
+        from awm_amd import main14b_2 as _m14
+        F16X3_NOTE_ = ("f16 dense MFMA peak 2500 TFLOP/s / 3 f16 piece products per product")
+        pmc14 = PMC_MAIN14B2 if batch == 128 else None
+        work = lambda a: (2.0 * a[6] * a[7] * a[9] * a[12] * a[13], 4.0 * a[6] * (a[7] * a[8] + a[16] * a[17]))
+        fp32 = dict(timer=LaunchTimer(lib, "wm_gconv", lambda a: a[12] > 64 and a[13] > 64 and a[12] % 4 == 0, work),
+                    kernel="gconv2_kernel<2,2,2> (wm_gconv, 128 x 128 output tiles: implicit-GEMM Conv1d / ConvTranspose1d / data "
+                           "gradients of the wide main14b_2 layers on the fp32 matrix cores; achieved = sum of algorithmic FLOPs / "
+                           "sum of launch times)",
+                    peak=PEAK_FP32_MFMA_TFLOPS, note=FP32_NOTE, pmc=pmc14, pmc_prefixes=("gconv2_kernel<2, 2, 2",))
+        # wm_gwgrad args: A Bx G dbias slab NB Ca Cb La Lb K P ...: G[a][b][k] = sum_{nb,t} A[nb][a][t] Bx[nb][b][t + k - P]
+        wg = dict(timer=LaunchTimer(lib, "wm_gwgrad", lambda a: True,
+                                    lambda a: (2.0 * a[5] * a[6] * a[7] * a[10] * a[8], 4.0 * a[5] * (a[6] * a[8] + a[7] * a[9]))),
+                  kernel="gwgrad2_kernel (wm_gwgrad: every weight gradient of the variant, deterministic split-K GEMM on the fp32 matrix "
+                         "cores; all launches; since the convolutions moved to the f16 split the largest family of the step)",
+                  peak=PEAK_FP32_MFMA_TFLOPS, note=FP32_NOTE, pmc=pmc14, pmc_prefixes=("gwgrad2_kernel<",))
+        if not (_m14._GCONV["f16x3"] and bf_mode):
+            return [fp32, wg]
+        # wm_gconv_h: the same argument positions (wph in place of wp)
+        h = dict(timer=LaunchTimer(lib, "wm_gconv_h", lambda a: a[12] > 64 and a[13] > 64, work),
+                 kernel="gconvh_kernel<2,2,2,*> (wm_gconv_h, 128 x 128 output tiles: implicit-GEMM Conv1d / ConvTranspose1d / data gradients "
+                        "of the wide main14b_2 layers as f16 two-piece split products on v_mfma_f32_32x32x16_f16, fp32 accumulate; achieved = "
+                        "sum of algorithmic FLOPs / sum of launch times)",
+                 peak=PEAK_BF16_MFMA_TFLOPS / 3.0, note=F16X3_NOTE_, pmc=pmc14, pmc_prefixes=("gconvh_kernel<2, 2, 2",))
+        return [h, wg]
     if not bf_mode:
         return [dict(timer=LaunchTimer(lib, "wm_conv64", lambda a: a[14] == 3 and a[16] == 0,
                                        lambda a: (2.0 * 64 * 64 * 3 * a[13] * a[12], 2.0 * 64 * a[13] * 4 * a[12])),
