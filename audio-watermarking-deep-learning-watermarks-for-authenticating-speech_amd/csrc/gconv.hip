@@ -356,6 +356,7 @@ struct GConvHArgs {
     GConvArgs g;
     const unsigned short* wph;      // [2 pieces][Cin / 16][K][Mtot][16] f16, then {ws, 1 / ws}
     const float* gscale;            // {gs, 1 / gs} or null
+    float* ymax;                    // optional: max |y| over everything the launch stores (atomic max of non-negative floats as ints; zeroed by the caller)
 };
 
 template <int MW, int WM, int WN, int XRH>   // XRH: staged window elements (channel pairs) per thread, 8 XW <= 256 XRH
@@ -501,6 +502,7 @@ __global__ __launch_bounds__(256) void gconvh_kernel(GConvHArgs ha) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] *= dinv;
 
     // ---- epilogue (gconv2_kernel's): + bias + per-clip vector + residual, ELU / ELU', (pixel-shuffled) store
+    float vmax = 0.f;
     const size_t clip = (size_t)nb * a.Cout * a.Lout;
     const wm_srd_t sy = make_srd(a.y + clip, (size_t)a.Cout * a.Lout * sizeof(float));
     const wm_srd_t sr = make_srd(a.res ? a.res + clip : a.y + clip, (size_t)a.Cout * a.Lout * sizeof(float));
@@ -567,8 +569,16 @@ __global__ __launch_bounds__(256) void gconvh_kernel(GConvHArgs ha) {
 #pragma unroll
             for (int r8 = 0; r8 < 8; ++r8)
 #pragma unroll
-                for (int j = 0; j < WN; ++j) buf_store(sy, acc[i][j][rh + r8], off[r8][j], 0u);
+                for (int j = 0; j < WN; ++j) {
+                    buf_store(sy, acc[i][j][rh + r8], off[r8][j], 0u);
+                    vmax = fmaxf(vmax, off[r8][j] != 0xffffffffu ? fabsf(acc[i][j][rh + r8]) : 0.f);
+                }
         }
+    }
+    if (ha.ymax) {                                   // the next consumer's gradient scale without a pass over y
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
+        if (lane == 0 && vmax == vmax && vmax < 3.0e38f) atomicMax(reinterpret_cast<int*>(ha.ymax), __float_as_int(vmax));
     }
 }
 
@@ -1234,7 +1244,7 @@ int wm_gconv(const float* x, const float* wp, const float* bias, const float* ve
 // the kernel's window limits (the caller then uses wm_gconv).
 int wm_gconv_h(const float* x, const void* wph, const float* bias, const float* vec, const float* res, float* y, int NB,
                int Cin, int Lin, int K, int S, int P, int Mtot, int Nout, int st, int shp, int Cout, int Lout, int act,
-               const float* x2, int Cin1, int nph, const float* gscale, hipStream_t stream) {
+               const float* x2, int Cin1, int nph, const float* gscale, float* ymax, hipStream_t stream) {
     if (NB <= 0 || Cin <= 0 || (Cin & 15) || K <= 0 || K > 16 || S <= 0 || S > 8 || Mtot <= 0 || Nout <= 0 || st < 1 || st > 8 || Lin <= 0 ||
         Lin >= (1 << 24) || NB > 65535 || Mtot >= 8192 || !wph)
         return (int)hipErrorInvalidValue;
@@ -1242,7 +1252,7 @@ int wm_gconv_h(const float* x, const void* wph, const float* bias, const float* 
     if (nph > st || (x2 && (Cin1 <= 0 || Cin1 >= Cin || (Cin1 & 15)))) return (int)hipErrorInvalidValue;
     GConvHArgs ha{GConvArgs{x, nullptr, bias, vec, res, y, NB, Cin, Lin, K, S, P, Mtot, Nout, st, shp, Cout, Lout, act, 0, 0, x2,
                             x2 ? Cin1 : Cin, nph},
-                  reinterpret_cast<const unsigned short*>(wph), gscale};
+                  reinterpret_cast<const unsigned short*>(wph), gscale, ymax};
     int rc;
     if (Nout <= 64) rc = Mtot > 64 ? launch_gconvh<2, 2, 1>(ha, stream) : launch_gconvh<2, 1, 1>(ha, stream);
     else if (Mtot > 64) rc = launch_gconvh<2, 2, 2>(ha, stream);

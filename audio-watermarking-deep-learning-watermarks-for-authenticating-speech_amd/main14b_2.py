@@ -44,14 +44,18 @@ def _gconv_raw(x, wp, bias, K, S, P, Mtot, Nout, st, shp, Cout, Lout, act=0, res
     if _GCONV["f16x3"] and Cin % 16 == 0 and Cin_tot % 16 == 0 and ops.conv_bf16x6():
         wph = torch.empty(2 * Cin_tot * K * Mtot + 4, dtype=torch.int16, device=x.device)
         lib.wm_gconv_pack_h(_p(wp), _p(wph), _p(_f32(1024, device=x.device)), Cin_tot, K, Mtot, _stream())
-        gsc = None
+        gsc = ymax = None
         if grad_in:
-            gsc = ops.gscale_absmax(x)
+            gsc = ops.gscale_of(x)                   # the producer's maximum when it left one (below), else one pass over x
             if x2 is not None:                       # one scale for both gradient sources: the smaller of the two
-                g2 = ops.gscale_absmax(x2)
+                g2 = ops.gscale_of(x2)
                 gsc = torch.stack([torch.minimum(gsc[0], g2[0]), torch.maximum(gsc[1], g2[1])])
+            if out is None:                          # y is a gradient too: leave max |y| for its consumer (a fresh y: every element is stored)
+                ymax = torch.zeros(1, dtype=torch.float32, device=x.device)
         lib.wm_gconv_h(_p(x), _p(wph), _p(bias), _p(vec), _p(res), _p(y), NB, Cin_tot, Lin, K, S, P, Mtot, Nout, st, shp, Cout, Lout, act,
-                       _p(x2), Cin if x2 is not None else 0, nph, _p(gsc), _stream())
+                       _p(x2), Cin if x2 is not None else 0, nph, _p(gsc), _p(ymax), _stream())
+        if ymax is not None:
+            ops._note_gmax(y, ymax)
         return y
     lib.wm_gconv(_p(x), _p(wp), _p(bias), _p(vec), _p(res), _p(y), NB, Cin_tot, Lin, K, S, P, Mtot, Nout, st, shp, Cout, Lout, act,
                  _p(x2), Cin if x2 is not None else 0, nph, _stream())

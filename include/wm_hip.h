@@ -264,7 +264,9 @@ int wm_gconv(const float* x, const float* wp, const float* bias, const float* ve
  * +-6e4 --, NULL for activations (split unscaled). */
 int wm_gconv_h(const float* x, const void* wph, const float* bias, const float* vec, const float* res, float* y, int NB,
                int Cin, int Lin, int K, int S, int P, int Mtot, int Nout, int st, int shp, int Cout, int Lout, int act,
-               const float* x2, int Cin1, int nph, const float* gscale, wm_stream_t stream);
+               const float* x2, int Cin1, int nph, const float* gscale, float* ymax, wm_stream_t stream);
+/* ymax (optional, ONE float zeroed by the caller): receives max |y| over everything the launch stores (atomic max) -- the gradient scale
+ * of whatever consumes y next comes from wm_gscale_from_max(ymax, 1, ...) instead of a pass over y */
 /* wph: 2 * Cin * K * Mtot f16 ([piece][Cin / 16][K][Mtot][16]: w * ws, ws = the power of two with max |w| ws in (2^9, 2^10]) followed by
  * {ws, 1 / ws} as two floats; scratch >= 1024 floats */
 int wm_gconv_pack_h(const float* wp, void* wph, float* scratch, int Cin, int K, int Mtot, wm_stream_t stream);
