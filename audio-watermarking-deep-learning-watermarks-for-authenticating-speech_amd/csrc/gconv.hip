@@ -611,9 +611,16 @@ int launch_gconvh(GConvHArgs ha, hipStream_t stream) {
 
 // f16 two-piece image of a wm_gconv weight matrix wp [Cin * K][Mtot] (row ci * K + tap): out[piece][ci / 16][tap][m][ci % 16];
 // the scale {ws, 1 / ws} sits behind the image (written by gscale_from_max beforehand)
-__global__ __launch_bounds__(256) void gconv_pack_h_kernel(const float* __restrict__ wp, unsigned short* __restrict__ out, int Cin, int K, int Mtot) {
+// (ws_fixed > 0: that scale is used and written behind the image by workgroup 0 -- no pass for max |w|)
+// mode -1: wp is the wm_gconv matrix [Cin * K][Mtot].  mode 0 / 1: wp is a Conv1d weight w [Cout][Cin_w][K] itself and the re-indexing of
+// the host mirror happens here -- 0 forward (GEMM channel = ci, row = co), 1 stride-1 data gradient (GEMM channel = co, row = ci, taps
+// flipped): the permute / flip / contiguous launches of the mirror disappear
+__global__ __launch_bounds__(256) void gconv_pack_h_kernel(const float* __restrict__ wp, unsigned short* __restrict__ out, int Cin, int K, int Mtot,
+                                                           float ws_fixed, int mode) {
     const size_t n = (size_t)Cin * K * Mtot, piece = n;
-    const float ws = reinterpret_cast<const float*>(out + 2 * piece)[0];
+    float* tail = reinterpret_cast<float*>(out + 2 * piece);
+    const float ws = ws_fixed > 0.f ? ws_fixed : tail[0];
+    if (ws_fixed > 0.f && blockIdx.x == 0 && threadIdx.x == 0) { tail[0] = ws_fixed; tail[1] = 1.f / ws_fixed; }
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
         // i walks the OUTPUT image: ((c K + tap) Mtot + m) * 16 + e
         const int e = (int)(i & 15);
@@ -621,7 +628,11 @@ __global__ __launch_bounds__(256) void gconv_pack_h_kernel(const float* __restri
         const int m = (int)(q % Mtot);
         const size_t ct = q / Mtot;
         const int tap = (int)(ct % K), c = (int)(ct / K);
-        const float v = wp[((size_t)(16 * c + e) * K + tap) * Mtot + m] * ws;
+        const int qch = 16 * c + e;                  // GEMM input channel
+        const size_t src = mode < 0 ? ((size_t)qch * K + tap) * Mtot + m
+                         : mode == 0 ? ((size_t)m * Cin + qch) * K + tap                    // w[co = m][ci = q][tap]
+                                     : ((size_t)qch * Mtot + m) * K + (K - 1 - tap);        // w[co = q][ci = m][K - 1 - tap]
+        const float v = __builtin_amdgcn_fmed3f(wp[src] * ws, -6.0e4f, 6.0e4f);
         const _Float16 hi = (_Float16)v;
         const _Float16 lo = (_Float16)(v - (float)hi);
         out[i] = __builtin_bit_cast(unsigned short, hi);
@@ -1264,14 +1275,30 @@ int wm_gconv_h(const float* x, const void* wph, const float* bias, const float* 
 
 // f16 image of wp [Cin * K][Mtot] for wm_gconv_h: wph holds 2 * Cin * K * Mtot f16 + 2 floats; scratch >= 1024 floats
 int wm_gconv_pack_h(const float* wp, void* wph, float* scratch, int Cin, int K, int Mtot, hipStream_t stream) {
-    if (!wp || !wph || !scratch || Cin <= 0 || (Cin & 15) || K <= 0 || Mtot <= 0) return (int)hipErrorInvalidValue;
+    if (!wp || !wph || Cin <= 0 || (Cin & 15) || K <= 0 || Mtot <= 0) return (int)hipErrorInvalidValue;
     const long long n = (long long)Cin * K * Mtot;
     unsigned short* out = reinterpret_cast<unsigned short*>(wph);
     float* tail = reinterpret_cast<float*>(out + 2 * n);
-    int rc = wm_gscale_absmax(wp, n, scratch, 10.0f, tail, stream);       // max |w| ws in (2^9, 2^10]
-    if (rc) return rc;
+    // scratch == NULL: the fixed scale 2^8 (one launch).  Weights of magnitude 4e-6 ... 250 keep a normal hi piece and lose nothing that an
+    // fp32 product would keep: the scale only has to hold the pieces inside f16's 30 binades; larger weights saturate at +-6e4 / 2^8
+    if (scratch) {
+        int rc = wm_gscale_absmax(wp, n, scratch, 10.0f, tail, stream);   // max |w| ws in (2^9, 2^10]
+        if (rc) return rc;
+    }
     const int grid = (int)((n + 255) / 256 < 512 ? (n + 255) / 256 : 512);
-    hipLaunchKernelGGL(gconv_pack_h_kernel, dim3(grid), dim3(256), 0, stream, wp, out, Cin, K, Mtot);
+    hipLaunchKernelGGL(gconv_pack_h_kernel, dim3(grid), dim3(256), 0, stream, wp, out, Cin, K, Mtot, scratch ? 0.f : 256.f, -1);
+    WM_CHECK_LAUNCH();
+    return 0;
+}
+
+// the same image straight from a Conv1d weight w [Cout][Cin][K] (fixed scale 2^8): mode 0 = the forward matrix (GEMM channels Cin, rows
+// Cout), mode 1 = the stride-1 data-gradient matrix (GEMM channels Cout, rows Cin, taps flipped).  wph: 2 * Cout * Cin * K f16 + 2 floats
+int wm_gconv_pack_h_conv(const float* w, void* wph, int Cout, int Cin, int K, int mode, hipStream_t stream) {
+    const int gch = mode == 0 ? Cin : Cout, rows = mode == 0 ? Cout : Cin;
+    if (!w || !wph || (mode != 0 && mode != 1) || Cout <= 0 || Cin <= 0 || K <= 0 || (gch & 15)) return (int)hipErrorInvalidValue;
+    const long long n = (long long)Cout * Cin * K;
+    const int grid = (int)((n + 255) / 256 < 512 ? (n + 255) / 256 : 512);
+    hipLaunchKernelGGL(gconv_pack_h_kernel, dim3(grid), dim3(256), 0, stream, w, reinterpret_cast<unsigned short*>(wph), gch, K, rows, 256.f, mode);
     WM_CHECK_LAUNCH();
     return 0;
 }

@@ -37,13 +37,28 @@ def set_gconv_f16x3(on: bool):
     _GCONV["f16x3"] = bool(on)
 
 
-def _gconv_raw(x, wp, bias, K, S, P, Mtot, Nout, st, shp, Cout, Lout, act=0, res=None, vec=None, x2=None, nph=0, out=None, grad_in=False):
+def _h_ok(cin):
+    """the f16 two-piece build of the generic convolution takes this layer (GEMM channel count a multiple of 16)"""
+    return _GCONV["f16x3"] and cin % 16 == 0 and ops.conv_bf16x6()
+
+
+def _pack_h_conv(w, mode):
+    """f16 image of a Conv1d weight for wm_gconv_h without the mirror's permute / flip / contiguous launches"""
+    Cout, Cin, K = w.shape
+    wph = torch.empty(2 * Cout * Cin * K + 4, dtype=torch.int16, device=w.device)
+    lib.wm_gconv_pack_h_conv(_p(w), _p(wph), Cout, Cin, K, mode, _stream())
+    return wph
+
+
+def _gconv_raw(x, wp, bias, K, S, P, Mtot, Nout, st, shp, Cout, Lout, act=0, res=None, vec=None, x2=None, nph=0, out=None, grad_in=False,
+               wph=None):
     NB, Cin, Lin = x.shape
     y = _f32(NB, Cout, Lout, device=x.device) if out is None else out
     Cin_tot = Cin + (x2.shape[1] if x2 is not None else 0)
-    if _GCONV["f16x3"] and Cin % 16 == 0 and Cin_tot % 16 == 0 and ops.conv_bf16x6():
-        wph = torch.empty(2 * Cin_tot * K * Mtot + 4, dtype=torch.int16, device=x.device)
-        lib.wm_gconv_pack_h(_p(wp), _p(wph), _p(_f32(1024, device=x.device)), Cin_tot, K, Mtot, _stream())
+    if wph is not None or (_GCONV["f16x3"] and Cin % 16 == 0 and Cin_tot % 16 == 0 and ops.conv_bf16x6()):
+        if wph is None:
+            wph = torch.empty(2 * Cin_tot * K * Mtot + 4, dtype=torch.int16, device=x.device)
+            lib.wm_gconv_pack_h(_p(wp), _p(wph), None, Cin_tot, K, Mtot, _stream())   # fixed scale 2^8: one launch per weight image
         gsc = ymax = None
         if grad_in:
             gsc = ops.gscale_of(x)                   # the producer's maximum when it left one (below), else one pass over x
@@ -85,6 +100,8 @@ def _conv_fwd(x, w, bias, stride, padding, act=0, res=None, vec=None):
             return _c64_conv(x, w, 0, bias, res, 6 if res is not None else 5)
         return _c64_conv(x, w, 0, bias, None, 0)
     Lout = (x.shape[2] + 2 * padding - K) // stride + 1
+    if _h_ok(Cin) and w.is_contiguous():
+        return _gconv_raw(x, None, bias, K, stride, padding, Cout, Lout, 1, 0, Cout, Lout, act, res, vec, wph=_pack_h_conv(w, 0))
     wp = w.permute(1, 2, 0).reshape(Cin * K, Cout).contiguous()
     return _gconv_raw(x, wp, bias, K, stride, padding, Cout, Lout, 1, 0, Cout, Lout, act, res, vec)
 
@@ -95,6 +112,9 @@ def _conv_dgrad(g, w, stride, padding, Lin, res=None, act=0, out=None):
     Cout, Cin, K = w.shape
     if out is None and _c64_ok(w, stride, padding, Lin) and g.shape[2] == Lin:
         return _c64_conv(g, w, 1, None, res, 7 if act == 2 else (2 if res is not None else 3))
+    if stride == 1 and _h_ok(Cout) and w.is_contiguous():
+        return _gconv_raw(g, None, None, K, 1, K - 1 - padding, Cin, Lin, 1, 0, Cin, Lin, act, res, None, None, 0, out, grad_in=True,
+                          wph=_pack_h_conv(w, 1))
     if stride == 1:
         wp = w.flip(2).permute(0, 2, 1).reshape(Cout * K, Cin).contiguous()             # rows (co, kk): W[co][ci][K-1-kk]
         return _gconv_raw(g, wp, None, K, 1, K - 1 - padding, Cin, Lin, 1, 0, Cin, Lin, act, res, None, None, 0, out, grad_in=True)

@@ -267,9 +267,13 @@ int wm_gconv_h(const float* x, const void* wph, const float* bias, const float* 
                const float* x2, int Cin1, int nph, const float* gscale, float* ymax, wm_stream_t stream);
 /* ymax (optional, ONE float zeroed by the caller): receives max |y| over everything the launch stores (atomic max) -- the gradient scale
  * of whatever consumes y next comes from wm_gscale_from_max(ymax, 1, ...) instead of a pass over y */
-/* wph: 2 * Cin * K * Mtot f16 ([piece][Cin / 16][K][Mtot][16]: w * ws, ws = the power of two with max |w| ws in (2^9, 2^10]) followed by
- * {ws, 1 / ws} as two floats; scratch >= 1024 floats */
+/* wph: 2 * Cin * K * Mtot f16 ([piece][Cin / 16][K][Mtot][16]: w * ws) followed by {ws, 1 / ws} as two floats.  scratch (>= 1024 floats):
+ * ws = the power of two with max |w| ws in (2^9, 2^10] (a pass over wp); scratch NULL: ws = 2^8 fixed, one launch -- what the host mirror
+ * uses: the scale only has to keep the two pieces inside the f16 range, which 2^8 does for max |w| between 4e-6 and 250 */
 int wm_gconv_pack_h(const float* wp, void* wph, float* scratch, int Cin, int K, int Mtot, wm_stream_t stream);
+/* the same image straight from a Conv1d weight w [Cout][Cin][K], fixed scale 2^8: mode 0 = the forward matrix (wp[ci K + k][co] = w[co][ci][k]),
+ * mode 1 = the stride-1 data-gradient matrix (wp[co K + kk][ci] = w[co][ci][K - 1 - kk]); the GEMM channel count (Cin | Cout) % 16 == 0 */
+int wm_gconv_pack_h_conv(const float* w, void* wph, int Cout, int Cin, int K, int mode, wm_stream_t stream);
 /* generic weight gradient, one stride-1 GEMM with the taps folded into the column index (deterministic: split-K partial
  * tiles in `slab`, then a fixed-order fp64 reduce -- no float atomics):
  *   G[a][b][k] (+)= sum_{nb,t} A[nb][a][t] * Bx[nb][b][t + k - P],  dbias[a] (+)= sum A   (Conv1d stride 1: A = dL/dy,
