@@ -365,6 +365,12 @@ def run_workload(model, mode, batch, steps, warmup, rank, world, dev, dist, torc
             dist.barrier()
         torch.cuda.synchronize()
 
+    # no cyclic-GC pass inside the timed region: a generation-2 collection of this process (torch's import alone leaves a few million
+    # tracked objects) takes 85-300 ms -- two to six steps -- and lands wherever the allocation counters put it
+    # (tests/diag_coldstart.py: one 133-ms step in 300, none with the collector off)
+    import gc
+    gc.collect()
+    gc.disable()
     fence()
     for e in timers:
         e["timer"].on = True
@@ -373,6 +379,7 @@ def run_workload(model, mode, batch, steps, warmup, rank, world, dev, dist, torc
         out = step()
     fence()
     dt = time.perf_counter() - t0
+    gc.enable()
     for e in timers:
         e["timer"].on = False
         e["timer"].restore()
