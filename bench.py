@@ -479,10 +479,11 @@ def main():
                 "config": {"workload": workload_name(args.model, args.mode, args.batch, world),
                            "batch_per_gpu": args.batch, "global_batch": args.batch * world, "clip_len": T,
                            "optimizer": "torch.optim.Adam" if args.torch_adam else "fused flat Adam (wm_adam_step)",
-                           "conv_arithmetic": ("64->64 convs (k3 and k7: fwd, dgrad, wgrad) and the LSTM input projection: bf16x6 split on "
-                                               "bf16 MFMA, fp32 accumulate (2.7e-7 vs fp64; native fp32 MFMA 2.5e-7); ResBlock backward "
-                                               "(data + weight gradients): f16 two-piece split, three products, fp32 accumulate "
-                                               "(within 2e-6 of the bf16x6 gradients)")
+                           "conv_arithmetic": ("64->64 convs (k3 ResBlock forward + fused data / weight gradient, k7 ConvTranspose forward / "
+                                               "dgrad / wgrad, inference ResBlock): f16 two-piece split, three piece products per product on "
+                                               "v_mfma_f32_32x32x16_f16, fp32 accumulate (error vs fp64 within 3x of bf16x6's 2.7e-7; native fp32 "
+                                               "MFMA 2.5e-7); LSTM projection / dx / weight gradients and the ragged-length fallbacks: bf16x6 "
+                                               "split on bf16 MFMA")
                            if (args.model == "main16" and bf_mode) else "native fp32 MFMA",
                            "parallelism": f"dp{world}" if world > 1 else "single"},
                 "loss": round(r["loss"], 6), "roofline": r["roofline"]}
