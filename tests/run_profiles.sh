@@ -27,6 +27,8 @@ if [ -f "$P/libwm_hip_stamp.so" ]; then
   for m in random zeros random; do echo "== operands: $m"; python3 tests/diag_stamp_dw.py 256 $m 2>&1 | grep -v amdgpu.ids | grep -v "    wave"; done > $out/dwgrad_stamps.txt
 fi
 if [ -f "$P/libwm_lstm_stamp.so" ]; then python3 tests/diag_stamp_lstm.py 256 2>&1 | grep -v amdgpu.ids > $out/lstm_step_budget.txt; fi
+# package power / clock level while one kernel family runs back to back (the power-limit evidence of DESIGN.md section 8)
+for w in dwgrad lstm bnrelu; do echo "== $w"; timeout -k 5 60 python3 tests/diag_power.py $w 2>&1 | grep -v amdgpu.ids | tail -3; done > $out/power_clock.txt
 # keep what travels back small: counter CSVs only
 find $out -name "*kernel_trace.csv" -size +20M -delete
 du -sh $out
