@@ -326,6 +326,9 @@ def kernel_timers(lib, model, mode, bf_mode, batch):
               peak=(PEAK_BF16_MFMA_TFLOPS / 3.0) if h else BF16X6_PEAK,
               note=F16X3_NOTE if h else BF16X6_NOTE,
               pmc=pmc16, pmc_prefixes=("dwgrad64bf_kernel<",))
+    dw["limited_by"] = ("package power: launched back to back this kernel holds the package at its 1400 W limit with a lowered clock "
+                        "(profiles/r03_power_clock.txt); in-kernel stamps: the same 5.75 K cycles per tile at 1.01 GHz on dense operands and "
+                        "1.26 GHz on all-zero ones (profiles/r03_dwgrad_stamps.txt) -- neither the HBM nor the MFMA fraction can reach 1")
     return [dw, fwd]
 
 
@@ -351,6 +354,8 @@ def roofline_of(entry):
                  "mfma_peak_note": entry["note"],
                  "achieved_over_fp32_mfma_peak_157TF": round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
                  "achieved_over_bf16x6_ceiling_416.7TF": round(ach / BF16X6_PEAK, 4)})
+    if entry.get("limited_by"):
+        head["limited_by"] = entry["limited_by"]
     return head
 
 
